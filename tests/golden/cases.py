@@ -1,0 +1,119 @@
+"""Case tables and closed-form input generators shared by make_golden.py (which runs the
+reference) and the tests (which never do).  No reference import here."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from oracle import stgcn_oracle as O  # noqa: E402
+
+GRAPH_CASES = [(l, s, 1, 1) for l in ("openpose", "ntu-rgb+d", "ntu_edge") for s in ("uniform", "distance", "spatial")]
+GRAPH_CASES += [("ntu-rgb+d", "spatial", 2, 1), ("openpose", "distance", 2, 1), ("ntu-rgb+d", "distance", 2, 2),
+                ("openpose", "spatial", 2, 2), ("ntu-rgb+d", "uniform", 2, 1)]
+
+# (name, layout, strategy, dense_A, B, Cin, Cout, T)
+GCN_CASES = [
+    ("ntu_spatial_3_8_t9", "ntu-rgb+d", "spatial", False, 2, 3, 8, 9),
+    ("ntu_spatial_8_16_t20", "ntu-rgb+d", "spatial", False, 2, 8, 16, 20),
+    ("ntu_dense_8_16_t37", "ntu-rgb+d", "spatial", True, 1, 8, 16, 37),
+    ("kin_spatial_3_16_t20", "openpose", "spatial", False, 2, 3, 16, 20),
+    ("kin_uniform_8_8_t9", "openpose", "uniform", False, 3, 8, 8, 9),
+    ("kin_distance_8_16_t37", "openpose", "distance", True, 1, 8, 16, 37),
+    ("ntu_spatial_64_64_t12", "ntu-rgb+d", "spatial", False, 2, 64, 64, 12),
+    ("ntu_spatial_64_128_t10", "ntu-rgb+d", "spatial", True, 1, 64, 128, 10),
+]
+
+# (name, layout, cin, cout, stride, residual, B, T, training)
+BLOCK_CASES = [
+    ("ntu_none_3_64_s1_train", "ntu-rgb+d", 3, 64, 1, False, 2, 20, True),
+    ("ntu_id_64_64_s1_train", "ntu-rgb+d", 64, 64, 1, True, 2, 21, True),
+    ("ntu_conv_64_128_s2_train", "ntu-rgb+d", 64, 128, 2, True, 2, 20, True),
+    ("ntu_conv_64_128_s2_oddT_train", "ntu-rgb+d", 64, 128, 2, True, 2, 37, True),
+    ("kin_id_64_64_s1_eval", "openpose", 64, 64, 1, True, 2, 20, False),
+    ("kin_conv_128_256_s2_oddT_eval", "openpose", 128, 256, 2, True, 1, 19, False),
+    ("kin_id_128_128_s1_train", "openpose", 128, 128, 1, True, 1, 24, True),
+]
+
+# (name, layout, num_class, N, T, M, training)
+MODEL_CASES = [
+    ("ntu_small_train", "ntu-rgb+d", 60, 2, 24, 2, True),
+    ("kin_small_train_oddT", "openpose", 400, 2, 38, 2, True),     # 38 -> 19 -> 10
+    ("ntu_small_eval", "ntu-rgb+d", 60, 2, 24, 2, False),
+    ("ntu_full_train", "ntu-rgb+d", 60, 2, 300, 2, True),
+    ("kin_full_eval", "openpose", 400, 2, 300, 2, False),
+    ("kin_t150_train", "openpose", 400, 2, 150, 2, True),          # 150 -> 75 -> 38
+]
+
+
+def t64(a):
+    return torch.tensor(np.asarray(a), dtype=torch.float64)
+
+
+def compact(v):
+    """Fixture storage form: float32; tensors above 65536 elements keep every 7th element of
+    the flattened array (tests apply the same rule through oracle-side helper compact_like)."""
+    a = np.asarray(v.detach().numpy() if isinstance(v, torch.Tensor) else v)
+    if a.size > 65536:
+        a = a.reshape(-1)[::7]
+    return a.astype(np.float32)
+
+
+def gcn_inputs(case, tag0):
+    name, lay, strat, dense, B, Cin, Cout, T = case
+    A0 = O.build_graph(lay, strat)["A"]
+    K, V = A0.shape[0], A0.shape[1]
+    if dense:
+        A = O.det_uniform(A0.shape, tag0 + 1, -0.5, 0.5)
+    else:
+        A = A0 * O.det_uniform(A0.shape, tag0 + 1, 0.5, 1.5)
+    x = O.det_uniform((B, Cin, T, V), tag0 + 2)
+    W = O.det_uniform((K * Cout, Cin), tag0 + 3) * (1.5 / np.sqrt(Cin))
+    b = O.det_uniform((K * Cout,), tag0 + 4, -0.2, 0.2)
+    dy = O.det_uniform((B, Cout, T, V), tag0 + 5)
+    return t64(x), t64(A), t64(W), t64(b), t64(dy)
+
+
+def block_inputs(case, tag0):
+    name, lay, cin, cout, stride, residual, B, T, training = case
+    A0 = O.build_graph(lay, "spatial")["A"]
+    K, V = A0.shape[0], A0.shape[1]
+    A = A0 * O.det_uniform(A0.shape, tag0 + 1, 0.5, 1.5)
+    x = O.det_uniform((B, cin, T, V), tag0 + 2)
+    kind = O.block_residual_kind(cin, cout, stride, residual)
+    p, bufs = {}, {}
+    shapes = {"gcn.conv.weight": (K * cout, cin, 1, 1), "gcn.conv.bias": (K * cout,),
+              "tcn.0.weight": (cout,), "tcn.0.bias": (cout,),
+              "tcn.2.weight": (cout, cout, 9, 1), "tcn.2.bias": (cout,),
+              "tcn.3.weight": (cout,), "tcn.3.bias": (cout,)}
+    bn_names = ["tcn.0", "tcn.3"]
+    if kind == "conv":
+        shapes.update({"residual.0.weight": (cout, cin, 1, 1), "residual.0.bias": (cout,),
+                       "residual.1.weight": (cout,), "residual.1.bias": (cout,)})
+        bn_names.append("residual.1")
+    for j, (k, shp) in enumerate(shapes.items()):
+        if len(shp) == 4:
+            v = O.det_uniform(shp, tag0 + 10 + j) * (1.5 / np.sqrt(np.prod(shp[1:])))
+        elif k.endswith(".weight"):
+            v = O.det_uniform(shp, tag0 + 10 + j, 0.8, 1.2)
+        else:
+            v = O.det_uniform(shp, tag0 + 10 + j, -0.2, 0.2)
+        p[k] = t64(v)
+    for j, bnn in enumerate(bn_names):
+        bufs[bnn + ".running_mean"] = t64(O.det_uniform((cout,), tag0 + 40 + j, -0.2, 0.2))
+        bufs[bnn + ".running_var"] = t64(O.det_uniform((cout,), tag0 + 50 + j, 0.5, 1.5))
+    To = (T - 1) // stride + 1
+    dout = O.det_uniform((B, cout, To, V), tag0 + 3)
+    return t64(x), t64(A), p, bufs, t64(dout), kind
+
+
+def model_inputs(ci):
+    name, lay, ncls, N, T, M, training = MODEL_CASES[ci]
+    V = O.graph_edges(lay)[0]
+    x = O.det_input(N, 3, T, V, M, tag=900 + ci)
+    labels = torch.tensor([(7 * i + 3) % ncls for i in range(N)])
+    return x, labels

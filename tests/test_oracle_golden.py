@@ -1,0 +1,137 @@
+"""CPU: the oracle restatement against the golden vectors produced by the reference's own
+modules (tests/golden/make_golden.py).  Storage precision of the fixtures is float32."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import stgcn_oracle as O
+from tests.golden import cases as C
+
+TOL = 2e-6   # float32 storage of float64 reference outputs
+
+
+def rel(a, b):
+    a = np.asarray(a, dtype=np.float64).reshape(-1)
+    b = np.asarray(b, dtype=np.float64).reshape(-1)
+    return np.abs(a - b).max() / (np.abs(b).max() + 1e-30)
+
+
+@pytest.mark.parametrize("case", C.GRAPH_CASES, ids=lambda c: "%s-%s-%d-%d" % c)
+def test_graph(golden, case):
+    lay, strat, mh, dil = case
+    ref = golden["graph"]["%s|%s|%d|%d" % case]
+    g = O.build_graph(lay, strat, mh, dil)
+    assert g["A"].shape == ref.shape
+    assert np.array_equal(g["A"], ref)          # bit-exact float64
+    # every column of sum_k A_k sums to one (column-normalised adjacency)
+    assert np.allclose(g["A"].sum(axis=(0, 1)), 1.0)
+
+
+def test_graph_errors():
+    with pytest.raises(ValueError):
+        O.build_graph("nope", "spatial")
+    with pytest.raises(ValueError):
+        O.build_graph("openpose", "nope")
+
+
+@pytest.mark.parametrize("ci", range(len(C.GCN_CASES)), ids=[c[0] for c in C.GCN_CASES])
+def test_gcn_op(golden, ci):
+    case = C.GCN_CASES[ci]
+    x, A, W, b, dy = C.gcn_inputs(case, 1000 + 10 * ci)
+    y = O.gcn_forward(x, A, W, b)
+    dx, dW, db, dA = O.gcn_backward(x, A, W, b, dy)
+    for k, v in dict(y=y, dx=dx, dW=dW, db=db, dA=dA).items():
+        assert rel(C.compact(v), golden["gcn_op"][case[0] + "/" + k]) < TOL, k
+
+
+@pytest.mark.parametrize("ci", range(len(C.BLOCK_CASES)), ids=[c[0] for c in C.BLOCK_CASES])
+def test_block(golden, ci):
+    case = C.BLOCK_CASES[ci]
+    name, lay, cin, cout, stride, residual, B, T, training = case
+    x, A, p, bufs, dout, kind = C.block_inputs(case, 5000 + 100 * ci)
+    out, cache, nb = O.block_forward(x, A, p, bufs, stride, kind, training)
+    dx, dA, g = O.block_backward(dout, p, cache, stride, kind, training)
+    mine = {"out": out, "dx": dx, "dA": dA}
+    mine.update({"g:" + k: v for k, v in g.items()})
+    mine.update({"buf:" + k: v for k, v in nb.items()})
+    G = golden["block"]
+    checked = 0
+    for key in G.files:
+        if not key.startswith(name + "/"):
+            continue
+        k = key[len(name) + 1:]
+        if training and k in ("g:tcn.2.bias", "g:residual.0.bias"):
+            assert np.abs(C.compact(mine[k])).max() < 1e-6   # exactly zero up to rounding
+        else:
+            assert rel(C.compact(mine[k]), G[key]) < TOL, k
+        checked += 1
+    assert checked >= 11
+
+
+@pytest.mark.parametrize("ci", [0, 1, 2], ids=[c[0] for c in C.MODEL_CASES[:3]])
+def test_model_small(golden, ci):
+    _check_model(golden, ci)
+
+
+@pytest.mark.parametrize("ci", [3], ids=[C.MODEL_CASES[3][0]])
+def test_model_full_ntu(golden, ci):
+    _check_model(golden, ci)
+
+
+def _check_model(golden, ci):
+    name, lay, ncls, N, T, M, training = C.MODEL_CASES[ci]
+    g = O.build_graph(lay, "spatial")
+    sd = O.det_state(3, ncls, g["A"], True)
+    x, labels = C.model_inputs(ci)
+    logits, cache, newb = O.model_forward(sd, x, training)
+    loss, dlog = O.cross_entropy(logits, labels)
+    G = golden["model"]
+    assert rel(logits, G[name + "/logits"]) < 1e-9
+    assert abs(loss.item() - float(G[name + "/loss"])) < 1e-9
+    if training:
+        grads = O.model_backward(sd, cache, dlog, True)
+        for k in O.param_names(sd):
+            gr = grads[k]
+            ref_norm = float(G[name + "/gnorm:" + k])
+            if k.endswith("tcn.2.bias") or k.endswith("residual.0.bias"):
+                assert gr.abs().max().item() < 1e-9
+                continue
+            assert abs(gr.norm().item() - ref_norm) <= 1e-8 * ref_norm + 1e-14, k
+            flat = gr.reshape(-1)
+            samp = flat[:: max(1, flat.numel() // 257)].numpy()
+            assert rel(samp, G[name + "/gsample:" + k]) < 1e-7, k
+        for key in G.files:
+            if key.startswith(name + "/buf:"):
+                assert rel(newb[key.split("buf:")[1]], G[key]) < 1e-9
+    if name.endswith("small_eval"):
+        o2, f2 = O.model_forward(sd, x, False, return_feature=True)
+        assert rel(o2, G[name + "/feat_output"]) < TOL
+        assert rel(f2, G[name + "/feat_feature"]) < TOL
+
+
+def test_sgd_steps(golden):
+    G = golden["sgd"]
+    g = O.build_graph("ntu-rgb+d", "spatial")
+    sd = O.det_state(3, 60, g["A"], True)
+    moms = {}
+    for step in range(3):
+        x = O.det_input(2, 3, 24, 25, 2, tag=1200 + step)
+        labels = torch.tensor([(5 * i + step) % 60 for i in range(2)])
+        logits, cache, newb = O.model_forward(sd, x, True)
+        loss, dlog = O.cross_entropy(logits, labels)
+        assert abs(loss.item() - float(G["loss%d" % step])) < 1e-7
+        grads = O.model_backward(sd, cache, dlog, True)
+        prm = {k: sd[k] for k in O.param_names(sd)}
+        O.sgd_nesterov_step(prm, grads, moms, 0.1)
+        sd.update(prm)
+        sd.update(newb)
+    for k in ("fcn.bias", "edge_importance.3", "st_gcn_networks.0.gcn.conv.weight"):
+        assert rel(sd[k], G["p:" + k]) < 1e-6
+
+
+def test_dropout_mask_rate():
+    m = O.dropout_keep_mask(200000, 1234, 0.5)
+    assert abs(m.mean() - 0.5) < 0.01
+    m2 = O.dropout_keep_mask(200000, 1235, 0.5)
+    assert (m != m2).mean() > 0.4
+    assert O.dropout_keep_mask(100, 1, 0.0).min() == 1.0

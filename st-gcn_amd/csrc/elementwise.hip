@@ -1,0 +1,625 @@
+// HBM-bound kernels of the st_gcn block: BatchNorm statistics finalisation, the fused
+// BN2-apply + dropout + residual + ReLU output stage and its backward, BN1 backward apply,
+// the input data_bn, the pooling / classifier head and the SGD update.
+// All activation tensors are channels-last [rows][C]; a thread owns one 16-byte channel vector
+// (fixed channels, so per-channel parameters live in registers and per-channel sums reduce in
+// registers -> LDS -> one double atomic per channel per workgroup).
+#include "stgcn_common.h"
+
+template <typename T> struct RowMap {
+    int cvs, rpi, cv, rl; bool active;
+    __device__ RowMap(int C) {
+        cvs = C / ET<T>::VEC;
+        rpi = 256 / cvs; if (rpi < 1) rpi = 1;
+        cv = threadIdx.x % cvs; rl = threadIdx.x / cvs;
+        active = rl < rpi && (int)threadIdx.x < cvs * rpi;
+    }
+};
+
+// sums[j] (per thread, NS floats for its VEC channels each) -> stats[s*C + c] += block total
+template <typename T, int NS>
+__device__ __forceinline__ void block_channel_reduce(float (*sums)[ET<T>::VEC], const RowMap<T>& m, int C, double* const* dst) {
+    constexpr int VEC = ET<T>::VEC;
+    __shared__ float red[256 * NS * VEC];
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) red[(threadIdx.x * NS + s) * VEC + j] = m.active ? sums[s][j] : 0.f;
+    __syncthreads();
+    if (m.active && m.rl == 0) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            if (!dst[s]) continue;
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                float t = 0.f;
+                for (int r = 0; r < m.rpi; ++r) t += red[((r * m.cvs + m.cv) * NS + s) * VEC + j];
+                atomicAdd(&dst[s][m.cv * VEC + j], (double)t);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// BatchNorm parameter finalisation (tiny)
+__global__ void bn_finalize_kernel(const double* stats, double count, const float* gamma, const float* beta,
+                                   float* rmean, float* rvar, float momentum, float eps,
+                                   float* mean, float* rstd, float* scale, float* shift, int C, int training) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float mu, var;
+    if (training) {
+        const double m = stats[c] / count;
+        double v = stats[C + c] / count - m * m;
+        if (v < 0) v = 0;
+        mu = (float)m; var = (float)v;
+        if (rmean) {
+            const double unb = count > 1 ? v * (count / (count - 1)) : v;
+            rmean[c] = (1.f - momentum) * rmean[c] + momentum * mu;
+            rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
+        }
+    } else {
+        mu = rmean[c]; var = rvar[c];
+    }
+    const float rs = 1.0f / sqrtf(var + eps);
+    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    mean[c] = mu; rstd[c] = rs;
+    scale[c] = g * rs;
+    shift[c] = b - mu * g * rs;
+}
+
+extern "C" int stgcn_bn_finalize(const double* stats, double count, const float* gamma, const float* beta,
+                                 float* running_mean, float* running_var, float momentum, float eps,
+                                 float* mean, float* rstd, float* scale, float* shift, int C, int training, void* stream) {
+    if (!mean || !rstd || !scale || !shift || C <= 0) return STGCN_ERR_ARG;
+    if (training && (!stats || count <= 0)) return STGCN_ERR_ARG;
+    if (!training && (!running_mean || !running_var)) return STGCN_ERR_ARG;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, (hipStream_t)stream,
+                       stats, count, gamma, beta, running_mean, running_var, momentum, eps, mean, rstd, scale, shift, C, training);
+    return hipGetLastError() == hipSuccess ? STGCN_OK : STGCN_ERR_LAUNCH;
+}
+
+// double sums -> float parameter gradients (dgamma = stats[1], dbeta = stats[0])
+__global__ void stats_to_grads_kernel(const double* stats, float* dgamma, float* dbeta, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    if (dbeta) dbeta[c] = (float)stats[c];
+    if (dgamma) dgamma[c] = (float)stats[C + c];
+}
+extern "C" int stgcn_stats_to_grads(const double* stats, float* dgamma, float* dbeta, int C, void* stream) {
+    if (!stats || C <= 0) return STGCN_ERR_ARG;
+    hipLaunchKernelGGL(stats_to_grads_kernel, dim3((C + 127) / 128), dim3(128), 0, (hipStream_t)stream, stats, dgamma, dbeta, C);
+    return hipGetLastError() == hipSuccess ? STGCN_OK : STGCN_ERR_LAUNCH;
+}
+
+// ------------------------------------------------------------------------------------------
+// Block output stage:  out = relu( (s2*o + b2) * keep/(1-p) + res' ),  res' = sr*res + br | res | 0
+struct BlockOutArgs {
+    const void* o; const void* res; void* out;
+    const float* s2; const float* b2; const float* sr; const float* br;
+    size_t rows; int C; uint32_t seed, thr; float keep_scale;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void block_out_fwd_kernel(BlockOutArgs a) {
+    constexpr int VEC = ET<T>::VEC;
+    RowMap<T> m(a.C);
+    if (!m.active) return;
+    float s2[VEC], b2[VEC], sr[VEC], br[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+        const int c = m.cv * VEC + j;
+        s2[j] = a.s2[c]; b2[j] = a.b2[c];
+        sr[j] = a.sr ? a.sr[c] : 1.f; br[j] = a.br ? a.br[c] : 0.f;
+    }
+    for (size_t row = (size_t)blockIdx.x * m.rpi + m.rl; row < a.rows; row += (size_t)gridDim.x * m.rpi) {
+        const size_t off = row * a.C + m.cv * VEC;
+        float f[VEC], r[VEC];
+        unpack16<T>(*(const i32x4*)((const T*)a.o + off), f);
+        if (a.res) unpack16<T>(*(const i32x4*)((const T*)a.res + off), r);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            float q = fmaf(f[j], s2[j], b2[j]);
+            if (a.thr) q = drop_keep(off + j, a.seed, a.thr) ? q * a.keep_scale : 0.f;
+            if (a.res) q += fmaf(r[j], sr[j], br[j]);
+            f[j] = fmaxf(q, 0.f);
+        }
+        *(i32x4*)((T*)a.out + off) = pack16<T>(f);
+    }
+}
+
+static inline unsigned ew_grid(size_t rows, int rows_per_block) {
+    size_t g = (rows + rows_per_block - 1) / rows_per_block;
+    if (g > 2048) g = 2048;
+    if (g < 1) g = 1;
+    return (unsigned)g;
+}
+template <typename T> static inline bool ew_ok(int C) {
+    const int VEC = ET<T>::VEC;
+    return C > 0 && C % VEC == 0 && C / VEC <= 256;
+}
+template <typename T> static inline int ew_rpi(int C) { int r = 256 / (C / ET<T>::VEC); return r < 1 ? 1 : r; }
+
+static inline uint32_t drop_thr(float p) {
+    if (p <= 0.f) return 0u;
+    double t = (double)p * 4294967296.0;
+    if (t > 4294967295.0) t = 4294967295.0;
+    return (uint32_t)t;
+}
+
+extern "C" int stgcn_block_out_fwd(int dtype, const void* o, const void* res, void* out,
+                                   const float* scale2, const float* shift2, const float* res_scale, const float* res_shift,
+                                   size_t rows, int C, float drop_p, uint32_t seed, void* stream) {
+    if (!o || !out || !scale2 || !shift2 || drop_p < 0.f || drop_p >= 1.f) return STGCN_ERR_ARG;
+    BlockOutArgs a;
+    a.o = o; a.res = res; a.out = out; a.s2 = scale2; a.b2 = shift2; a.sr = res_scale; a.br = res_shift;
+    a.rows = rows; a.C = C; a.seed = seed; a.thr = drop_thr(drop_p); a.keep_scale = 1.f / (1.f - drop_p);
+    if (dtype == STGCN_BF16) {
+        if (!ew_ok<bf16>(C)) return STGCN_ERR_ARG;
+        hipLaunchKernelGGL(block_out_fwd_kernel<bf16>, dim3(ew_grid(rows, ew_rpi<bf16>(C))), dim3(256), 0, (hipStream_t)stream, a);
+    } else if (dtype == STGCN_F32) {
+        if (!ew_ok<float>(C)) return STGCN_ERR_ARG;
+        hipLaunchKernelGGL(block_out_fwd_kernel<float>, dim3(ew_grid(rows, ew_rpi<float>(C))), dim3(256), 0, (hipStream_t)stream, a);
+    } else return STGCN_ERR_ARG;
+    return hipGetLastError() == hipSuccess ? STGCN_OK : STGCN_ERR_LAUNCH;
+}
+
+// Backward of the output stage, pass 1: per-channel sums
+//   g  = dout * (out > 0);  gd = g * keep/(1-p)
+//   stats2 = [sum gd, sum gd*ohat]  (ohat = (o - mean2) * rstd2)
+//   statsr = [sum g,  sum g*rhat]   (only for the conv residual: rhat = (r - meanr) * rstdr)
+struct BlockOutBwdArgs {
+    const void* dout; const void* out; const void* o; const void* r;
+    const float* mean2; const float* rstd2; const float* gamma2;
+    const float* meanr; const float* rstdr; const float* gammar;
+    double* stats2; double* statsr;
+    void* dO; void* dR; void* g;
+    double* dbias_o; double* dbias_r;
+    size_t rows; int C; uint32_t seed, thr; float keep_scale; double count; int training;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void block_out_bwd_reduce_kernel(BlockOutBwdArgs a) {
+    constexpr int VEC = ET<T>::VEC;
+    RowMap<T> m(a.C);
+    float sums[4][VEC];
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) sums[s][j] = 0.f;
+    if (m.active) {
+        float mu2[VEC], rs2[VEC], mur[VEC], rsr[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            const int c = m.cv * VEC + j;
+            mu2[j] = a.mean2[c]; rs2[j] = a.rstd2[c];
+            mur[j] = a.r ? a.meanr[c] : 0.f; rsr[j] = a.r ? a.rstdr[c] : 0.f;
+        }
+        for (size_t row = (size_t)blockIdx.x * m.rpi + m.rl; row < a.rows; row += (size_t)gridDim.x * m.rpi) {
+            const size_t off = row * a.C + m.cv * VEC;
+            float d[VEC], y[VEC], o[VEC], r[VEC];
+            unpack16<T>(*(const i32x4*)((const T*)a.dout + off), d);
+            unpack16<T>(*(const i32x4*)((const T*)a.out + off), y);
+            unpack16<T>(*(const i32x4*)((const T*)a.o + off), o);
+            if (a.r) unpack16<T>(*(const i32x4*)((const T*)a.r + off), r);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                const float g = y[j] > 0.f ? d[j] : 0.f;
+                float gd = g;
+                if (a.thr) gd = drop_keep(off + j, a.seed, a.thr) ? g * a.keep_scale : 0.f;
+                sums[0][j] += gd;
+                sums[1][j] += gd * ((o[j] - mu2[j]) * rs2[j]);
+                if (a.r) {
+                    sums[2][j] += g;
+                    sums[3][j] += g * ((r[j] - mur[j]) * rsr[j]);
+                }
+            }
+        }
+    }
+    double* dst[4] = {a.stats2, a.stats2 + a.C, a.r ? a.statsr : nullptr, a.r ? a.statsr + a.C : nullptr};
+    block_channel_reduce<T, 4>(sums, m, a.C, dst);
+}
+
+// pass 2: dO = BN2 backward of gd; dR = BNr backward of g (conv residual); g copy (identity residual)
+template <typename T>
+__global__ __launch_bounds__(256) void block_out_bwd_apply_kernel(BlockOutBwdArgs a) {
+    constexpr int VEC = ET<T>::VEC;
+    RowMap<T> m(a.C);
+    float sums[2][VEC];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) sums[s][j] = 0.f;
+    if (m.active) {
+        float mu2[VEC], rs2[VEC], k2[VEC], m1[VEC], m2[VEC];
+        float mur[VEC], rsr[VEC], kr[VEC], n1[VEC], n2[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            const int c = m.cv * VEC + j;
+            mu2[j] = a.mean2[c]; rs2[j] = a.rstd2[c]; k2[j] = a.gamma2[c] * rs2[j];
+            m1[j] = a.training ? (float)(a.stats2[c] / a.count) : 0.f;
+            m2[j] = a.training ? (float)(a.stats2[a.C + c] / a.count) : 0.f;
+            if (a.dR) {
+                mur[j] = a.meanr[c]; rsr[j] = a.rstdr[c]; kr[j] = a.gammar[c] * rsr[j];
+                n1[j] = a.training ? (float)(a.statsr[c] / a.count) : 0.f;
+                n2[j] = a.training ? (float)(a.statsr[a.C + c] / a.count) : 0.f;
+            } else { mur[j] = rsr[j] = kr[j] = n1[j] = n2[j] = 0.f; }
+        }
+        for (size_t row = (size_t)blockIdx.x * m.rpi + m.rl; row < a.rows; row += (size_t)gridDim.x * m.rpi) {
+            const size_t off = row * a.C + m.cv * VEC;
+            float d[VEC], y[VEC], o[VEC], r[VEC], gg[VEC], dr[VEC];
+            unpack16<T>(*(const i32x4*)((const T*)a.dout + off), d);
+            unpack16<T>(*(const i32x4*)((const T*)a.out + off), y);
+            unpack16<T>(*(const i32x4*)((const T*)a.o + off), o);
+            if (a.dR) unpack16<T>(*(const i32x4*)((const T*)a.r + off), r);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                const float g = y[j] > 0.f ? d[j] : 0.f;
+                gg[j] = g;
+                float gd = g;
+                if (a.thr) gd = drop_keep(off + j, a.seed, a.thr) ? g * a.keep_scale : 0.f;
+                const float oh = (o[j] - mu2[j]) * rs2[j];
+                o[j] = k2[j] * (gd - m1[j] - oh * m2[j]);
+                sums[0][j] += o[j];
+                if (a.dR) {
+                    const float rh = (r[j] - mur[j]) * rsr[j];
+                    dr[j] = kr[j] * (g - n1[j] - rh * n2[j]);
+                    sums[1][j] += dr[j];
+                }
+            }
+            *(i32x4*)((T*)a.dO + off) = pack16<T>(o);
+            if (a.dR) *(i32x4*)((T*)a.dR + off) = pack16<T>(dr);
+            if (a.g) *(i32x4*)((T*)a.g + off) = pack16<T>(gg);
+        }
+    }
+    double* dst[2] = {a.dbias_o, a.dR ? a.dbias_r : nullptr};
+    block_channel_reduce<T, 2>(sums, m, a.C, dst);
+}
+
+extern "C" int stgcn_block_out_bwd(int dtype, int pass, const void* dout, const void* out, const void* o, const void* r,
+                                   const float* mean2, const float* rstd2, const float* gamma2,
+                                   const float* meanr, const float* rstdr, const float* gammar,
+                                   double* stats2, double* statsr, void* dO, void* dR, void* g,
+                                   double* dbias_o, double* dbias_r,
+                                   size_t rows, int C, float drop_p, uint32_t seed, double count, int training, void* stream) {
+    if (!dout || !out || !o || !mean2 || !rstd2 || !stats2) return STGCN_ERR_ARG;
+    if (r && (!meanr || !rstdr || !statsr)) return STGCN_ERR_ARG;
+    BlockOutBwdArgs a;
+    a.dout = dout; a.out = out; a.o = o; a.r = r; a.mean2 = mean2; a.rstd2 = rstd2; a.gamma2 = gamma2;
+    a.meanr = meanr; a.rstdr = rstdr; a.gammar = gammar; a.stats2 = stats2; a.statsr = statsr;
+    a.dO = dO; a.dR = dR; a.g = g; a.dbias_o = dbias_o; a.dbias_r = dbias_r;
+    a.rows = rows; a.C = C; a.seed = seed; a.thr = drop_thr(drop_p); a.keep_scale = 1.f / (1.f - drop_p);
+    a.count = count; a.training = training;
+    if (pass == 1) {
+        if (!dO || !gamma2 || !dbias_o || (dR && (!r || !gammar || !dbias_r))) return STGCN_ERR_ARG;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == STGCN_BF16) {
+        if (!ew_ok<bf16>(C)) return STGCN_ERR_ARG;
+        const unsigned gr = ew_grid(rows, ew_rpi<bf16>(C));
+        if (pass == 0) hipLaunchKernelGGL(block_out_bwd_reduce_kernel<bf16>, dim3(gr), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL(block_out_bwd_apply_kernel<bf16>, dim3(gr), dim3(256), 0, st, a);
+    } else if (dtype == STGCN_F32) {
+        if (!ew_ok<float>(C)) return STGCN_ERR_ARG;
+        const unsigned gr = ew_grid(rows, ew_rpi<float>(C));
+        if (pass == 0) hipLaunchKernelGGL(block_out_bwd_reduce_kernel<float>, dim3(gr), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL(block_out_bwd_apply_kernel<float>, dim3(gr), dim3(256), 0, st, a);
+    } else return STGCN_ERR_ARG;
+    return hipGetLastError() == hipSuccess ? STGCN_OK : STGCN_ERR_LAUNCH;
+}
+
+// ------------------------------------------------------------------------------------------
+// BN backward apply (BN1):  dy = gamma*rstd*(g - S1/n - yhat*S2/n)   [eval: g*gamma*rstd]
+struct BnBwdArgs {
+    const void* g; const void* y; void* dy; const float* gamma; const float* mean; const float* rstd;
+    const double* stats; double count; size_t rows; int C; int training;
+};
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a) {
+    constexpr int VEC = ET<T>::VEC;
+    RowMap<T> m(a.C);
+    if (!m.active) return;
+    float mu[VEC], rs[VEC], kk[VEC], m1[VEC], m2[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+        const int c = m.cv * VEC + j;
+        mu[j] = a.mean[c]; rs[j] = a.rstd[c]; kk[j] = a.gamma[c] * rs[j];
+        m1[j] = a.training ? (float)(a.stats[c] / a.count) : 0.f;
+        m2[j] = a.training ? (float)(a.stats[a.C + c] / a.count) : 0.f;
+    }
+    for (size_t row = (size_t)blockIdx.x * m.rpi + m.rl; row < a.rows; row += (size_t)gridDim.x * m.rpi) {
+        const size_t off = row * a.C + m.cv * VEC;
+        float g[VEC], y[VEC];
+        unpack16<T>(*(const i32x4*)((const T*)a.g + off), g);
+        unpack16<T>(*(const i32x4*)((const T*)a.y + off), y);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) g[j] = kk[j] * (g[j] - m1[j] - ((y[j] - mu[j]) * rs[j]) * m2[j]);
+        *(i32x4*)((T*)a.dy + off) = pack16<T>(g);
+    }
+}
+extern "C" int stgcn_bn_bwd_apply(int dtype, const void* g, const void* y, void* dy, const float* gamma,
+                                  const float* mean, const float* rstd, const double* stats, double count,
+                                  size_t rows, int C, int training, void* stream) {
+    if (!g || !y || !dy || !gamma || !mean || !rstd || (training && !stats)) return STGCN_ERR_ARG;
+    BnBwdArgs a;
+    a.g = g; a.y = y; a.dy = dy; a.gamma = gamma; a.mean = mean; a.rstd = rstd; a.stats = stats; a.count = count;
+    a.rows = rows; a.C = C; a.training = training;
+    if (dtype == STGCN_BF16) {
+        if (!ew_ok<bf16>(C)) return STGCN_ERR_ARG;
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16>, dim3(ew_grid(rows, ew_rpi<bf16>(C))), dim3(256), 0, (hipStream_t)stream, a);
+    } else if (dtype == STGCN_F32) {
+        if (!ew_ok<float>(C)) return STGCN_ERR_ARG;
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(ew_grid(rows, ew_rpi<float>(C))), dim3(256), 0, (hipStream_t)stream, a);
+    } else return STGCN_ERR_ARG;
+    return hipGetLastError() == hipSuccess ? STGCN_OK : STGCN_ERR_LAUNCH;
+}
+
+// ------------------------------------------------------------------------------------------
+// data_bn: BatchNorm1d over channel index v*C + c of x[N, C, T, V, M] (f32), statistics over
+// (n, m, t); output is the channels-last [N*M][T][V][Cp] activation (Cp >= C, padding zero).
+__global__ __launch_bounds__(256) void data_bn_stats_kernel(const float* x, double* stats, int N, int C, int T, int V, int M) {
+    // one workgroup per (n, c, t-chunk); thread j walks the contiguous [t][v][m] slab
+    extern __shared__ float sh[];               // [2][V]
+    const int nc = blockIdx.x;                  // n*C + c
+    const int c = nc % C;
+    const int VM = V * M;
+    for (int i = threadIdx.x; i < 2 * V; i += blockDim.x) sh[i] = 0.f;
+    __syncthreads();
+    const int tchunk = (T + gridDim.y - 1) / gridDim.y;
+    const int t0 = blockIdx.y * tchunk, t1 = min(T, t0 + tchunk);
+    const float* base = x + (size_t)nc * T * VM;
+    // each thread keeps one (v) if VM divides the stride pattern; general: atomics in LDS
+    for (int i = t0 * VM + threadIdx.x; i < t1 * VM; i += blockDim.x) {
+        const float val = base[i];
+        const int v = (i % VM) / M;
+        atomicAdd(&sh[v], val);
+        atomicAdd(&sh[V + v], val * val);
+    }
+    __syncthreads();
+    const int VC = V * C;
+    for (int v = threadIdx.x; v < V; v += blockDim.x) {
+        atomicAdd(&stats[v * C + c], (double)sh[v]);
+        atomicAdd(&stats[VC + v * C + c], (double)sh[V + v]);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void data_bn_apply_kernel(const float* x, T* out, const float* scale, const float* shift,
+                                                           int N, int C, int T_, int V, int M, int Cp) {
+    // thread per output (b = n*M+m, t, v)
+    const size_t total = (size_t)N * M * T_ * V;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int v = (int)(i % V);
+        size_t rest = i / V;
+        const int t = (int)(rest % T_); rest /= T_;
+        const int mm = (int)(rest % M);
+        const int n = (int)(rest / M);
+        for (int c = 0; c < Cp; ++c) {
+            float val = 0.f;
+            if (c < C) {
+                const float xv = x[((((size_t)n * C + c) * T_ + t) * V + v) * M + mm];
+                val = fmaf(xv, scale[v * C + c], shift[v * C + c]);
+            }
+            store_elem<T>(out, i * Cp + c, val);
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void data_bn_bwd_kernel(const T* dx0, const float* x, const float* mean, const float* rstd,
+                                                         double* stats, int N, int C, int T_, int V, int M, int Cp) {
+    // one workgroup per (n*M+m, t-chunk): accumulate dbeta/dgamma per (v, c) in LDS, then double atomics
+    extern __shared__ float sh[];               // [2][V*C]
+    const int VC = V * C;
+    for (int i = threadIdx.x; i < 2 * VC; i += blockDim.x) sh[i] = 0.f;
+    __syncthreads();
+    const int b = blockIdx.x;
+    const int n = b / M, mm = b % M;
+    const int tchunk = (T_ + gridDim.y - 1) / gridDim.y;
+    const int t0 = blockIdx.y * tchunk, t1 = min(T_, t0 + tchunk);
+    for (int i = t0 * VC + threadIdx.x; i < t1 * VC; i += blockDim.x) {
+        const int c = i % C;
+        const int v = (i / C) % V;
+        const int t = i / VC;
+        const float d = load_elem<T>(dx0, (((size_t)b * T_ + t) * V + v) * Cp + c);
+        const float xv = x[((((size_t)n * C + c) * T_ + t) * V + v) * M + mm];
+        const int ch = v * C + c;
+        atomicAdd(&sh[ch], d);
+        atomicAdd(&sh[VC + ch], d * ((xv - mean[ch]) * rstd[ch]));
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * VC; i += blockDim.x) atomicAdd(&stats[i], (double)sh[i]);
+}
+
+extern "C" int stgcn_data_bn_stats(const float* x, double* stats, int N, int C, int T, int V, int M, void* stream) {
+    if (!x || !stats || N < 1 || C < 1 || T < 1 || V < 1 || M < 1) return STGCN_ERR_ARG;
+    int gy = (T + 31) / 32; if (gy > 16) gy = 16;
+    hipLaunchKernelGGL(data_bn_stats_kernel, dim3((unsigned)(N * C), (unsigned)gy), dim3(256), 2 * V * sizeof(float), (hipStream_t)stream, x, stats, N, C, T, V, M);
+    return hipGetLastError() == hipSuccess ? STGCN_OK : STGCN_ERR_LAUNCH;
+}
+extern "C" int stgcn_data_bn_apply(int dtype, const float* x, void* out, const float* scale, const float* shift,
+                                   int N, int C, int T, int V, int M, int Cp, void* stream) {
+    if (!x || !out || !scale || !shift || Cp < C) return STGCN_ERR_ARG;
+    const size_t total = (size_t)N * M * T * V;
+    unsigned g = (unsigned)((total + 255) / 256); if (g > 4096) g = 4096;
+    if (dtype == STGCN_BF16) hipLaunchKernelGGL(data_bn_apply_kernel<bf16>, dim3(g), dim3(256), 0, (hipStream_t)stream, x, (bf16*)out, scale, shift, N, C, T, V, M, Cp);
+    else if (dtype == STGCN_F32) hipLaunchKernelGGL(data_bn_apply_kernel<float>, dim3(g), dim3(256), 0, (hipStream_t)stream, x, (float*)out, scale, shift, N, C, T, V, M, Cp);
+    else return STGCN_ERR_ARG;
+    return hipGetLastError() == hipSuccess ? STGCN_OK : STGCN_ERR_LAUNCH;
+}
+extern "C" int stgcn_data_bn_bwd(int dtype, const void* dx0, const float* x, const float* mean, const float* rstd, double* stats,
+                                 int N, int C, int T, int V, int M, int Cp, void* stream) {
+    if (!dx0 || !x || !mean || !rstd || !stats || Cp < C) return STGCN_ERR_ARG;
+    int gy = (T + 31) / 32; if (gy > 16) gy = 16;
+    const size_t lds = 2 * (size_t)V * C * sizeof(float);
+    if (lds > 64 * 1024) return STGCN_ERR_ARG;
+    dim3 grid((unsigned)(N * M), (unsigned)gy);
+    if (dtype == STGCN_BF16) hipLaunchKernelGGL(data_bn_bwd_kernel<bf16>, grid, dim3(256), lds, (hipStream_t)stream, (const bf16*)dx0, x, mean, rstd, stats, N, C, T, V, M, Cp);
+    else if (dtype == STGCN_F32) hipLaunchKernelGGL(data_bn_bwd_kernel<float>, grid, dim3(256), lds, (hipStream_t)stream, (const float*)dx0, x, mean, rstd, stats, N, C, T, V, M, Cp);
+    else return STGCN_ERR_ARG;
+    return hipGetLastError() == hipSuccess ? STGCN_OK : STGCN_ERR_LAUNCH;
+}
+
+// ------------------------------------------------------------------------------------------
+// Head: global average pool over (T, V), mean over persons, 1x1 classifier.
+template <typename T>
+__global__ __launch_bounds__(256) void pool_fwd_kernel(const T* feat, float* pooled, int R, int C) {
+    // workgroup per (b, channel-vector group); feat [B][R][C]
+    constexpr int VEC = ET<T>::VEC;
+    RowMap<T> m(C);
+    float s[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) s[j] = 0.f;
+    const int b = blockIdx.x;
+    if (m.active)
+        for (int row = m.rl; row < R; row += m.rpi) {
+            float f[VEC];
+            unpack16<T>(*(const i32x4*)(feat + ((size_t)b * R + row) * C + m.cv * VEC), f);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) s[j] += f[j];
+        }
+    __shared__ float red[256 * VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) red[threadIdx.x * VEC + j] = m.active ? s[j] : 0.f;
+    __syncthreads();
+    if (m.active && m.rl == 0) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            float t = 0.f;
+            for (int r = 0; r < m.rpi; ++r) t += red[(r * m.cvs + m.cv) * VEC + j];
+            pooled[(size_t)b * C + m.cv * VEC + j] = t / (float)R;
+        }
+    }
+}
+extern "C" int stgcn_pool_fwd(int dtype, const void* feat, float* pooled, int B, int R, int C, void* stream) {
+    if (!feat || !pooled || B < 1 || R < 1) return STGCN_ERR_ARG;
+    if (dtype == STGCN_BF16) { if (!ew_ok<bf16>(C)) return STGCN_ERR_ARG; hipLaunchKernelGGL(pool_fwd_kernel<bf16>, dim3(B), dim3(256), 0, (hipStream_t)stream, (const bf16*)feat, pooled, R, C); }
+    else if (dtype == STGCN_F32) { if (!ew_ok<float>(C)) return STGCN_ERR_ARG; hipLaunchKernelGGL(pool_fwd_kernel<float>, dim3(B), dim3(256), 0, (hipStream_t)stream, (const float*)feat, pooled, R, C); }
+    else return STGCN_ERR_ARG;
+    return hipGetLastError() == hipSuccess ? STGCN_OK : STGCN_ERR_LAUNCH;
+}
+
+// logits[n][j] = bias[j] + sum_c W[j][c] * mean_m pooled[n*M+m][c]
+__global__ void head_fc_fwd_kernel(const float* pooled, const float* W, const float* bias, float* logits, int N, int M, int C, int ncls) {
+    const int n = blockIdx.x;
+    extern __shared__ float pm[];               // [C]
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float s = 0.f;
+        for (int mm = 0; mm < M; ++mm) s += pooled[((size_t)n * M + mm) * C + c];
+        pm[c] = s / (float)M;
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < ncls; j += blockDim.x) {
+        float s = bias ? bias[j] : 0.f;
+        for (int c = 0; c < C; ++c) s = fmaf(W[(size_t)j * C + c], pm[c], s);
+        logits[(size_t)n * ncls + j] = s;
+    }
+}
+// dW[j][c] = sum_n dlog[n][j]*pm[n][c]; db[j] = sum_n dlog[n][j]; dpm[n][c] = sum_j dlog[n][j] W[j][c]
+__global__ void head_fc_bwd_kernel(const float* dlog, const float* pooled, const float* W, float* dW, float* db, float* dpm,
+                                   int N, int M, int C, int ncls) {
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t nW = (size_t)ncls * C, nP = (size_t)N * C;
+    if (tid < nW) {
+        const int j = (int)(tid / C), c = (int)(tid % C);
+        float s = 0.f;
+        for (int n = 0; n < N; ++n) {
+            float pm = 0.f;
+            for (int mm = 0; mm < M; ++mm) pm += pooled[((size_t)n * M + mm) * C + c];
+            s = fmaf(dlog[(size_t)n * ncls + j], pm / (float)M, s);
+        }
+        dW[tid] = s;
+    } else if (tid < nW + nP) {
+        const size_t i = tid - nW;
+        const int n = (int)(i / C), c = (int)(i % C);
+        float s = 0.f;
+        for (int j = 0; j < ncls; ++j) s = fmaf(dlog[(size_t)n * ncls + j], W[(size_t)j * C + c], s);
+        dpm[i] = s;
+    } else if (tid < nW + nP + ncls) {
+        const int j = (int)(tid - nW - nP);
+        float s = 0.f;
+        for (int n = 0; n < N; ++n) s += dlog[(size_t)n * ncls + j];
+        db[j] = s;
+    }
+}
+// dfeat[b][row][c] = dpm[b / M][c] * scale    (scale = 1 / (M * R))
+template <typename T>
+__global__ __launch_bounds__(256) void pool_bwd_kernel(const float* dpm, T* dfeat, int R, int C, int M, float scale) {
+    constexpr int VEC = ET<T>::VEC;
+    RowMap<T> m(C);
+    if (!m.active) return;
+    const int b = blockIdx.x;
+    float f[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) f[j] = dpm[(size_t)(b / M) * C + m.cv * VEC + j] * scale;
+    const i32x4 v = pack16<T>(f);
+    for (int row = blockIdx.y * m.rpi + m.rl; row < R; row += gridDim.y * m.rpi)
+        *(i32x4*)(dfeat + ((size_t)b * R + row) * C + m.cv * VEC) = v;
+}
+extern "C" int stgcn_head_fc_fwd(const float* pooled, const float* W, const float* bias, float* logits, int N, int M, int C, int ncls, void* stream) {
+    if (!pooled || !W || !logits || C > 8192) return STGCN_ERR_ARG;
+    hipLaunchKernelGGL(head_fc_fwd_kernel, dim3(N), dim3(256), C * sizeof(float), (hipStream_t)stream, pooled, W, bias, logits, N, M, C, ncls);
+    return hipGetLastError() == hipSuccess ? STGCN_OK : STGCN_ERR_LAUNCH;
+}
+extern "C" int stgcn_head_fc_bwd(const float* dlogits, const float* pooled, const float* W, float* dW, float* db, float* dpm,
+                                 int N, int M, int C, int ncls, void* stream) {
+    if (!dlogits || !pooled || !W || !dW || !db || !dpm) return STGCN_ERR_ARG;
+    const size_t total = (size_t)ncls * C + (size_t)N * C + ncls;
+    hipLaunchKernelGGL(head_fc_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dlogits, pooled, W, dW, db, dpm, N, M, C, ncls);
+    return hipGetLastError() == hipSuccess ? STGCN_OK : STGCN_ERR_LAUNCH;
+}
+extern "C" int stgcn_pool_bwd(int dtype, const float* dpm, void* dfeat, int B, int R, int C, int M, void* stream) {
+    if (!dpm || !dfeat || B < 1 || R < 1 || M < 1) return STGCN_ERR_ARG;
+    const float scale = 1.f / ((float)M * (float)R);
+    dim3 grid((unsigned)B, 8);
+    if (dtype == STGCN_BF16) { if (!ew_ok<bf16>(C)) return STGCN_ERR_ARG; hipLaunchKernelGGL(pool_bwd_kernel<bf16>, grid, dim3(256), 0, (hipStream_t)stream, dpm, (bf16*)dfeat, R, C, M, scale); }
+    else if (dtype == STGCN_F32) { if (!ew_ok<float>(C)) return STGCN_ERR_ARG; hipLaunchKernelGGL(pool_bwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, dpm, (float*)dfeat, R, C, M, scale); }
+    else return STGCN_ERR_ARG;
+    return hipGetLastError() == hipSuccess ? STGCN_OK : STGCN_ERR_LAUNCH;
+}
+
+// ------------------------------------------------------------------------------------------
+// SGD with momentum / Nesterov / weight decay over a flat f32 buffer (torch.optim.SGD semantics).
+__global__ void sgd_kernel(float* p, const float* g, float* mom, size_t n, float lr, float momentum, float wd, int nesterov, int first, float gscale) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float w = p[i];
+        const float d = fmaf(wd, w, g[i] * gscale);
+        const float b = first ? d : fmaf(momentum, mom[i], d);
+        mom[i] = b;
+        const float step = nesterov ? fmaf(momentum, b, d) : b;
+        p[i] = w - lr * step;
+    }
+}
+extern "C" int stgcn_sgd_step(float* params, const float* grads, float* momentum_buf, size_t n,
+                              float lr, float momentum, float weight_decay, int nesterov, int first_step, float grad_scale, void* stream) {
+    if (!params || !grads || !momentum_buf) return STGCN_ERR_ARG;
+    if (n == 0) return STGCN_OK;
+    size_t g = (n + 255) / 256; if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(sgd_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, params, grads, momentum_buf, n, lr, momentum, weight_decay, nesterov, first_step, grad_scale);
+    return hipGetLastError() == hipSuccess ? STGCN_OK : STGCN_ERR_LAUNCH;
+}
+
+// ------------------------------------------------------------------------------------------
+extern "C" int stgcn_version(void) { return 1; }
+extern "C" const char* stgcn_arch(void) { return "gfx950"; }
+extern "C" int stgcn_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return -1; return n; }
+
+// Diagnostic: what ds_read_b64_tr_b16 hands each lane for a [32 rows][32 x 16-bit] LDS image whose
+// element (row, col) holds the raw pattern row*256 + col, addressed exactly as the wgrad kernels do.
+__global__ void probe_tr16_kernel(short* out) {
+    __shared__ __attribute__((aligned(16))) short img[32 * 40];
+    for (int i = threadIdx.x; i < 32 * 32; i += 64) img[(i >> 5) * 40 + (i & 31)] = (short)(((i >> 5) << 8) | (i & 31));
+    __syncthreads();
+    const int lane = threadIdx.x, h = lane >> 5;
+    const int q4 = (lane & 15) >> 2, p4 = lane & 3, g1 = (lane >> 4) & 1;
+    const int row0 = 8 * h + q4, col = 16 * g1 + 4 * p4;
+    const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(&img[row0 * 40 + col]));
+    const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(&img[(row0 + 4) * 40 + col]));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { out[lane * 8 + j] = v0[j]; out[lane * 8 + 4 + j] = v1[j]; }
+}
+extern "C" int stgcn_probe_tr16(short* out, void* stream) {
+    if (!out) return STGCN_ERR_ARG;
+    hipLaunchKernelGGL(probe_tr16_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, out);
+    return hipGetLastError() == hipSuccess ? STGCN_OK : STGCN_ERR_LAUNCH;
+}

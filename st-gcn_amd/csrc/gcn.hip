@@ -1,0 +1,606 @@
+// Graph convolution (1x1 K*C projection fused with the partitioned-adjacency aggregation)
+// and its parameter gradients, on MFMA, one skeleton frame per wave.
+//
+// gcn_fused:   out[f, a, n] = sum_k sum_b adj[k][a][b] * ( sum_c in[f, b, c] * w[k][n][c] + bias[k][n] )
+//   Forward uses adj[k][a=w][b=v] = A_eff[k][v][w], w[k][n=co][c=ci] = W[k*Cout+co][ci].
+//   Input gradient is the same kernel with adj[k][a=v][b=w] = A_eff[k][v][w], w[k][n=ci][c=co]
+//   = W[k*Cout+co][ci] and no bias.
+//   Per (frame, 32-column tile): the projection z_k (joints x columns, 32x32 accumulator) is
+//   computed with the frame's rows as the MFMA A operand straight from global memory (channels
+//   are contiguous), then each z_k accumulator is converted in registers into the B operand of the
+//   aggregation MFMA (the accumulator's row index -- the joint -- is the contraction index), so the
+//   K*C intermediate never leaves the register file.
+// gcn_agrad:   dA[k][v][w] = sum_{f, co} ( sum_ci W[k][co][ci] x[f,v,ci] + bias[k][co] ) * dy[f, w, co]
+// gcn_wgrad:   dW[k][co][ci] = sum_{f, v} (sum_w A_eff[k][v][w] dy[f,w,co]) * x[f, v, ci];  db[k][co] likewise.
+#include "stgcn_common.h"
+
+#define GCN_KMAX 3
+
+// ------------------------------------------------------------------------------------------
+struct GcnFusedArgs {
+    const void* in; const void* w; const float* adj; const float* bias; void* out; const void* add;
+    double* stats;
+    int NF, V, Cin, Nout, K, ntw;
+};
+
+// Adjacency operand fragments for the chained aggregation MFMA, built in LDS once per workgroup.
+//  bf16: entry (k, s2, lane) = 8 bf16: adj[k][a = lane&31][b = acc_row(8*s2 + j, lane>>5)], j = 0..7
+//  f32 : entry (k, r, lane)  = adj[k][lane&31][acc_row(r, lane>>5)]
+template <typename T>
+__device__ __forceinline__ void build_adj_chain_table(char* tab, const float* adj, int K, int V, int tid, int nthreads) {
+    if constexpr (ET<T>::IS_BF16) {
+        for (int e = tid; e < K * 2 * 64; e += nthreads) {
+            const int lane = e & 63, s2 = (e >> 6) & 1, k = e >> 7;
+            const int a = lane & 31, h = lane >> 5;
+            float f[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int b = acc_row(8 * s2 + j, h);
+                f[j] = (a < V && b < V) ? adj[((size_t)k * V + a) * V + b] : 0.f;
+            }
+            *(i32x4*)(tab + (size_t)e * 16) = pack16<bf16>(f);
+        }
+    } else {
+        for (int e = tid; e < K * 16 * 64; e += nthreads) {
+            const int lane = e & 63, r = (e >> 6) & 15, k = e >> 10;
+            const int a = lane & 31, h = lane >> 5;
+            const int b = acc_row(r, h);
+            ((float*)tab)[e] = (a < V && b < V) ? adj[((size_t)k * V + a) * V + b] : 0.f;
+        }
+    }
+}
+template <typename T> static inline size_t adj_chain_table_bytes(int K) {
+    return ET<T>::IS_BF16 ? (size_t)K * 2 * 64 * 16 : (size_t)K * 16 * 64 * 4;
+}
+
+// acc (rows = contraction index) -> B operand of the next MFMA; a_tab supplies the matching A operand
+template <typename T>
+__device__ __forceinline__ void chain_mma(f32x16& accy, const f32x16& accz, const char* tab_k, int lane) {
+    if constexpr (ET<T>::IS_BF16) {
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            i32x4 bfr;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bfr[j] = (int)pack_bf16x2(accz[8 * s2 + 2 * j], accz[8 * s2 + 2 * j + 1]);
+            const i32x4 afr = *(const i32x4*)(tab_k + ((size_t)s2 * 64 + lane) * 16);
+            accy = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(s16x8, afr), __builtin_bit_cast(s16x8, bfr), accy, 0, 0, 0);
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float av = ((const float*)tab_k)[r * 64 + lane];
+            accy = __builtin_amdgcn_mfma_f32_32x32x2f32(av, accz[r], accy, 0, 0, 0);
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gcn_fused_kernel(GcnFusedArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int ES = ET<T>::ES;
+    constexpr int KSTEP = ET<T>::KSTEP;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int V = a.V, K = a.K, Cin = a.Cin, Nout = a.Nout;
+    const int NTW = a.ntw;                       // 32-column tiles per workgroup
+    const int nbase = blockIdx.y * NTW * 32;
+    const int RSW = Cin * ES + 16;               // LDS row stride of the weight image
+    char* wl = smem;                             // [K][NTW*32][RSW]
+    char* tab = smem + (size_t)K * NTW * 32 * RSW;
+    const size_t tab_k_bytes = ET<T>::IS_BF16 ? 2 * 64 * 16 : 16 * 64 * 4;
+
+    // stage weights (rows beyond Nout are zero) and the adjacency fragments
+    {
+        const int ppr = Cin * ES / 16;           // 16-byte pieces per row
+        const int npieces = K * NTW * 32 * ppr;
+        for (int p = tid; p < npieces; p += 256) {
+            const int seg = p % ppr, row = p / ppr;
+            const int k = row / (NTW * 32), nl = row - k * NTW * 32;
+            const int n = nbase + nl;
+            i32x4 v = zero16();
+            if (n < Nout) v = *(const i32x4*)((const char*)a.w + (((size_t)k * Nout + n) * Cin) * ES + seg * 16);
+            *(i32x4*)(wl + (size_t)row * RSW + seg * 16) = v;
+        }
+        build_adj_chain_table<T>(tab, a.adj, K, V, tid, 256);
+    }
+    __syncthreads();
+
+    const int NA = Cin / KSTEP;                  // 32-byte k-steps per row
+    const int npass = (NA + 15) / 16;
+    float st1[4], st2[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { st1[i] = 0.f; st2[i] = 0.f; }
+
+    for (int f = blockIdx.x * 4 + wave; f < a.NF; f += gridDim.x * 4) {
+        const int brow = min(l31, V - 1);        // rows >= V duplicate the last joint; adj zeroes them
+        const char* ap = (const char*)a.in + (((size_t)f * V + brow) * Cin) * ES + h * 16;
+        i32x4 afr[16];
+        auto load_a = [&](int pass) {
+#pragma unroll
+            for (int s = 0; s < 16; ++s)
+                if (pass * 16 + s < NA) afr[s] = *(const i32x4*)(ap + (pass * 16 + s) * 32);
+        };
+        if (npass == 1) load_a(0);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            if (nt < NTW && nbase + nt * 32 < Nout) {
+                const int n = nbase + nt * 32 + l31;
+                f32x16 accy;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) accy[r] = 0.f;
+                for (int k = 0; k < K; ++k) {
+                    const float bv = (a.bias && n < Nout) ? a.bias[(size_t)k * Nout + n] : 0.f;
+                    f32x16 accz;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) accz[r] = bv;
+                    const char* wrow = wl + ((size_t)(k * NTW + nt) * 32 + l31) * RSW + h * 16;
+                    for (int pass = 0; pass < npass; ++pass) {
+                        if (npass > 1) load_a(pass);
+#pragma unroll
+                        for (int s = 0; s < 16; ++s) {
+                            if (pass * 16 + s < NA) {
+                                const i32x4 bfr = *(const i32x4*)(wrow + (pass * 16 + s) * 32);
+                                mma_step<T>(accz, afr[s], bfr);
+                            }
+                        }
+                    }
+                    chain_mma<T>(accy, accz, tab + (size_t)k * tab_k_bytes, lane);
+                }
+                // epilogue: lane = column n, register r = joint acc_row(r, h)
+                if (n < Nout) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int aj = acc_row(r, h);
+                        if (aj < V) {
+                            const size_t o = ((size_t)f * V + aj) * Nout + n;
+                            float val = accy[r];
+                            if (a.add) val += load_elem<T>((const T*)a.add, o);
+                            st1[nt] += val;
+                            st2[nt] += val * val;
+                            store_elem<T>((T*)a.out, o, val);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (a.stats) {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            if (nt < NTW) {
+                const int n = nbase + nt * 32 + l31;
+                const float s1 = st1[nt] + __shfl_xor(st1[nt], 32);
+                const float s2 = st2[nt] + __shfl_xor(st2[nt], 32);
+                if (h == 0 && n < Nout) {
+                    atomicAdd(&a.stats[n], (double)s1);
+                    atomicAdd(&a.stats[Nout + n], (double)s2);
+                }
+            }
+        }
+    }
+}
+
+template <typename T>
+static int gcn_fused_run(GcnFusedArgs& a, hipStream_t stream) {
+    constexpr int ES = ET<T>::ES, KSTEP = ET<T>::KSTEP;
+    if (a.Cin % KSTEP != 0 || a.Cin <= 0 || a.Cin > 32 * KSTEP || a.Nout <= 0 || a.K < 1 || a.K > 8 || a.V < 1 || a.V > 32 || a.NF < 1) return STGCN_ERR_ARG;
+    const size_t rsw = (size_t)a.Cin * ES + 16;
+    int ntw = 4;
+    while (ntw > 1 && ((size_t)a.K * ntw * 32 * rsw + adj_chain_table_bytes<T>(a.K) > 72 * 1024 || (ntw - 1) * 32 >= a.Nout)) --ntw;
+    const size_t lds = (size_t)a.K * ntw * 32 * rsw + adj_chain_table_bytes<T>(a.K);
+    if (lds > 160 * 1024) return STGCN_ERR_ARG;
+    a.ntw = ntw;
+    const int gy = ceil_div_i(a.Nout, ntw * 32);
+    int gx = ceil_div_i(a.NF, 4);
+    const int cap = max(1, 2048 / gy);
+    if (gx > cap) gx = cap;
+    auto kern = gcn_fused_kernel<T>;
+    static bool set = false;
+    if (!set) { if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return STGCN_ERR_LAUNCH; set = true; }
+    hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)gy), dim3(256), lds, stream, a);
+    return hipGetLastError() == hipSuccess ? STGCN_OK : STGCN_ERR_LAUNCH;
+}
+
+extern "C" int stgcn_gcn_fused(int dtype, const void* in, const void* w_packed, const float* adj, const float* bias,
+                               void* out, const void* add, double* stats,
+                               int NF, int V, int Cin, int Nout, int K, void* stream) {
+    if (!in || !w_packed || !adj || !out) return STGCN_ERR_ARG;
+    GcnFusedArgs a;
+    a.in = in; a.w = w_packed; a.adj = adj; a.bias = bias; a.out = out; a.add = add; a.stats = stats;
+    a.NF = NF; a.V = V; a.Cin = Cin; a.Nout = Nout; a.K = K; a.ntw = 1;
+    if (dtype == STGCN_BF16) return gcn_fused_run<bf16>(a, (hipStream_t)stream);
+    if (dtype == STGCN_F32) return gcn_fused_run<float>(a, (hipStream_t)stream);
+    return STGCN_ERR_ARG;
+}
+
+// ------------------------------------------------------------------------------------------
+// gcn_agrad
+struct GcnAgradArgs {
+    const void* x; const void* w; const float* bias; const void* dy; float* slab;
+    int NF, V, Cin, Cout, K, ntw;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void gcn_agrad_kernel(GcnAgradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int ES = ET<T>::ES;
+    constexpr int KSTEP = ET<T>::KSTEP;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int V = a.V, K = a.K, Cin = a.Cin, Cout = a.Cout;
+    const int NTW = a.ntw;
+    const int cbase = blockIdx.y * NTW * 32;
+    const int RSW = Cin * ES + 16;
+    char* wl = smem;                             // [K][NTW*32][RSW]
+    {
+        const int ppr = Cin * ES / 16;
+        const int npieces = K * NTW * 32 * ppr;
+        for (int p = tid; p < npieces; p += 256) {
+            const int seg = p % ppr, row = p / ppr;
+            const int k = row / (NTW * 32), nl = row - k * NTW * 32;
+            const int co = cbase + nl;
+            i32x4 v = zero16();
+            if (co < Cout) v = *(const i32x4*)((const char*)a.w + (((size_t)k * Cout + co) * Cin) * ES + seg * 16);
+            *(i32x4*)(wl + (size_t)row * RSW + seg * 16) = v;
+        }
+    }
+    __syncthreads();
+
+    const int NA = Cin / KSTEP;
+    const int npass = (NA + 15) / 16;
+    f32x16 accd[GCN_KMAX];
+#pragma unroll
+    for (int k = 0; k < GCN_KMAX; ++k)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accd[k][r] = 0.f;
+
+    for (int f = blockIdx.x * 4 + wave; f < a.NF; f += gridDim.x * 4) {
+        const int jrow = min(l31, V - 1);
+        const char* xp = (const char*)a.x + (((size_t)f * V + jrow) * Cin) * ES + h * 16;
+        const char* dyp = (const char*)a.dy + (((size_t)f * V + jrow) * Cout) * ES;
+        i32x4 xfr[16];
+        auto load_x = [&](int pass) {
+#pragma unroll
+            for (int s = 0; s < 16; ++s)
+                if (pass * 16 + s < NA) xfr[s] = *(const i32x4*)(xp + (pass * 16 + s) * 32);
+        };
+        if (npass == 1) load_x(0);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            if (nt < NTW && cbase + nt * 32 < Cout) {
+                const int c0 = cbase + nt * 32;
+                // dy operand for this co tile: element for acc register r is dy[f, w = lane, c0 + acc_row(r, h)]
+                float dyv[16];
+                if constexpr (ET<T>::IS_BF16) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {      // registers 4g..4g+3 are 4 consecutive channels
+                        const i32x2 raw = *(const i32x2*)(dyp + (size_t)(c0 + 8 * g + 4 * h) * 2);
+                        dyv[4 * g + 0] = __uint_as_float((uint32_t)raw[0] << 16);
+                        dyv[4 * g + 1] = __uint_as_float((uint32_t)raw[0] & 0xFFFF0000u);
+                        dyv[4 * g + 2] = __uint_as_float((uint32_t)raw[1] << 16);
+                        dyv[4 * g + 3] = __uint_as_float((uint32_t)raw[1] & 0xFFFF0000u);
+                    }
+                } else {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x4 raw = *(const f32x4*)(dyp + (size_t)(c0 + 8 * g + 4 * h) * 4);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) dyv[4 * g + j] = raw[j];
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < GCN_KMAX; ++k) {
+                    if (k < K) {
+                        // z^T tile: rows = co (registers), cols = joint v (lane)
+                        f32x16 accz;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int co = c0 + acc_row(r, h);
+                            accz[r] = (a.bias && co < Cout) ? a.bias[(size_t)k * Cout + co] : 0.f;
+                        }
+                        const char* wrow = wl + ((size_t)(k * NTW + nt) * 32 + l31) * RSW + h * 16;
+                        for (int pass = 0; pass < npass; ++pass) {
+                            if (npass > 1) load_x(pass);
+#pragma unroll
+                            for (int s = 0; s < 16; ++s) {
+                                if (pass * 16 + s < NA) {
+                                    const i32x4 wfr = *(const i32x4*)(wrow + (pass * 16 + s) * 32);
+                                    mma_step<T>(accz, wfr, xfr[s]);
+                                }
+                            }
+                        }
+                        // dA_k[v][w] += sum_co z^T[co][v] * dy[w][co]   (z^T as the A operand)
+                        if constexpr (ET<T>::IS_BF16) {
+#pragma unroll
+                            for (int s2 = 0; s2 < 2; ++s2) {
+                                i32x4 afr, bfr;
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) {
+                                    afr[j] = (int)pack_bf16x2(accz[8 * s2 + 2 * j], accz[8 * s2 + 2 * j + 1]);
+                                    bfr[j] = (int)pack_bf16x2(dyv[8 * s2 + 2 * j], dyv[8 * s2 + 2 * j + 1]);
+                                }
+                                accd[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(s16x8, afr), __builtin_bit_cast(s16x8, bfr), accd[k], 0, 0, 0);
+                            }
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < 16; ++r)
+                                accd[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(accz[r], dyv[r], accd[k], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    // accd[k]: row = v (registers), col = w (lane)
+    const size_t part = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave;
+#pragma unroll
+    for (int k = 0; k < GCN_KMAX; ++k) {
+        if (k < K) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int v = acc_row(r, h);
+                if (v < V && l31 < V) a.slab[((part * K + k) * V + v) * V + l31] = accd[k][r];
+            }
+        }
+    }
+}
+
+__global__ void sum_parts_kernel(const float* slab, float* out, int nparts, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int p = 0; p < nparts; ++p) s += slab[(size_t)p * n + i];
+        out[i] = s;
+    }
+}
+
+template <typename T>
+static int gcn_agrad_run(GcnAgradArgs& a, float* dA, size_t ws_bytes, hipStream_t stream) {
+    constexpr int ES = ET<T>::ES, KSTEP = ET<T>::KSTEP;
+    if (a.Cin % KSTEP != 0 || a.Cin <= 0 || a.Cin > 32 * KSTEP || a.Cout % 8 != 0 || a.K < 1 || a.K > GCN_KMAX || a.V < 1 || a.V > 32 || a.NF < 1) return STGCN_ERR_ARG;
+    const size_t rsw = (size_t)a.Cin * ES + 16;
+    int ntw = 4;
+    while (ntw > 1 && ((size_t)a.K * ntw * 32 * rsw > 72 * 1024 || (ntw - 1) * 32 >= a.Cout)) --ntw;
+    const size_t lds = (size_t)a.K * ntw * 32 * rsw;
+    if (lds > 160 * 1024) return STGCN_ERR_ARG;
+    a.ntw = ntw;
+    const int gy = ceil_div_i(a.Cout, ntw * 32);
+    int gx = ceil_div_i(a.NF, 4);
+    const int cap = max(1, 256 / gy);
+    if (gx > cap) gx = cap;
+    const size_t n = (size_t)a.K * a.V * a.V;
+    if ((size_t)gx * gy * 4 * n * sizeof(float) > ws_bytes) return STGCN_ERR_WORKSPACE;
+    auto kern = gcn_agrad_kernel<T>;
+    static bool set = false;
+    if (!set) { if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return STGCN_ERR_LAUNCH; set = true; }
+    hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)gy), dim3(256), lds, stream, a);
+    if (hipGetLastError() != hipSuccess) return STGCN_ERR_LAUNCH;
+    hipLaunchKernelGGL(sum_parts_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a.slab, dA, gx * gy * 4, n);
+    return hipGetLastError() == hipSuccess ? STGCN_OK : STGCN_ERR_LAUNCH;
+}
+
+extern "C" int stgcn_gcn_agrad(int dtype, const void* x, const void* w_packed, const float* bias, const void* dy,
+                               float* dA, int NF, int V, int Cin, int Cout, int K,
+                               void* workspace, size_t workspace_bytes, void* stream) {
+    if (!x || !w_packed || !dy || !dA || !workspace) return STGCN_ERR_ARG;
+    GcnAgradArgs a;
+    a.x = x; a.w = w_packed; a.bias = bias; a.dy = dy; a.slab = (float*)workspace;
+    a.NF = NF; a.V = V; a.Cin = Cin; a.Cout = Cout; a.K = K; a.ntw = 1;
+    if (dtype == STGCN_BF16) return gcn_agrad_run<bf16>(a, dA, workspace_bytes, (hipStream_t)stream);
+    if (dtype == STGCN_F32) return gcn_agrad_run<float>(a, dA, workspace_bytes, (hipStream_t)stream);
+    return STGCN_ERR_ARG;
+}
+
+// ------------------------------------------------------------------------------------------
+// gcn_wgrad
+struct GcnWgradArgs {
+    const void* x; const void* dy; const float* adj; float* slabW; float* slabB;
+    int NF, V, Cin, Cout, K, cig, iters;
+};
+
+// LDS per wave: dy image [32][DRS] (32 channels of one co tile) and x image [32][XRS] (cig channels);
+// rows >= V stay zero.  Then the adjacency A-operand table (natural contraction order).
+template <typename T>
+__global__ __launch_bounds__(256) void gcn_wgrad_kernel(GcnWgradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int ES = ET<T>::ES;
+    constexpr bool BF = ET<T>::IS_BF16;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int V = a.V, K = a.K, Cin = a.Cin, Cout = a.Cout, CIG = a.cig;
+    const int DRS = 32 * ES + 16, XRS = CIG * ES + 16;
+    const int img_bytes = 32 * DRS + 32 * XRS;
+    char* dimg = smem + (size_t)wave * img_bytes;
+    char* ximg = dimg + 32 * DRS;
+    char* tab = smem + (size_t)4 * img_bytes;    // bf16: [K][2][64] x 16 B ; f32: [K][32(w)][32(v)] floats
+    const int c0 = blockIdx.y * 32;              // co tile
+    const int i0 = blockIdx.z * CIG;             // ci group
+    const int CIT = (CIG + 31) / 32;             // 32-wide ci tiles in the group (1 or 2)
+
+    for (int p = tid; p < 4 * img_bytes / 16; p += 256) *(i32x4*)(smem + (size_t)p * 16) = zero16();
+    if constexpr (BF) {
+        for (int e = tid; e < K * 2 * 64; e += 256) {
+            const int ln = e & 63, s2 = (e >> 6) & 1, k = e >> 7;
+            const int v = ln & 31, hh = ln >> 5;
+            float f[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int w = 16 * s2 + 8 * hh + j;
+                f[j] = (v < V && w < V) ? a.adj[((size_t)k * V + v) * V + w] : 0.f;
+            }
+            *(i32x4*)(tab + (size_t)e * 16) = pack16<bf16>(f);
+        }
+    } else {
+        for (int e = tid; e < K * 32 * 32; e += 256) {
+            const int v = e & 31, w = (e >> 5) & 31, k = e >> 10;
+            ((float*)tab)[e] = (v < V && w < V) ? a.adj[((size_t)k * V + v) * V + w] : 0.f;
+        }
+    }
+    __syncthreads();
+
+    f32x16 accw[GCN_KMAX][2];
+    float dbacc[GCN_KMAX];
+#pragma unroll
+    for (int k = 0; k < GCN_KMAX; ++k) {
+        dbacc[k] = 0.f;
+#pragma unroll
+        for (int it = 0; it < 2; ++it)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accw[k][it][r] = 0.f;
+    }
+    const int q4 = (lane & 15) >> 2, p4 = lane & 3, g1 = (lane >> 4) & 1;
+    const int dppr = 32 * ES / 16, xppr = CIG * ES / 16;
+
+    for (int it0 = 0; it0 < a.iters; ++it0) {
+        const int f = (it0 * gridDim.x + blockIdx.x) * 4 + wave;
+        const bool fok = f < a.NF;
+        __syncthreads();                         // images of the previous frame fully consumed
+        for (int p = lane; p < V * dppr; p += 64) {
+            const int row = p / dppr, seg = p - row * dppr;
+            i32x4 v = zero16();
+            if (fok && c0 + seg * (16 / ES) < Cout)
+                v = *(const i32x4*)((const char*)a.dy + (((size_t)f * V + row) * Cout + c0) * ES + seg * 16);
+            *(i32x4*)(dimg + row * DRS + seg * 16) = v;
+        }
+        for (int p = lane; p < V * xppr; p += 64) {
+            const int row = p / xppr, seg = p - row * xppr;
+            i32x4 v = zero16();
+            if (fok) v = *(const i32x4*)((const char*)a.x + (((size_t)f * V + row) * Cin + i0) * ES + seg * 16);
+            *(i32x4*)(ximg + row * XRS + seg * 16) = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < GCN_KMAX; ++k) {
+            if (k < K) {
+                // dz = A_eff[k] (v x w) * dy (w x co): rows = v (registers), cols = co (lane)
+                f32x16 dz;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dz[r] = 0.f;
+                if constexpr (BF) {
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) {
+                        const i32x4 afr = *(const i32x4*)(tab + (((size_t)k * 2 + s2) * 64 + lane) * 16);
+                        const int row0 = 16 * s2 + 8 * h + q4;
+                        const int col = (16 * g1 + 4 * p4) * 2;
+                        const s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(dimg + row0 * DRS + col));
+                        const s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(dimg + (row0 + 4) * DRS + col));
+                        const s16x8 bfr = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+                        dz = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(s16x8, afr), bfr, dz, 0, 0, 0);
+                    }
+                } else {
+#pragma unroll
+                    for (int s = 0; s < 16; ++s) {
+                        const int w = 2 * s + h;
+                        const float av = ((const float*)tab)[((size_t)k * 32 + w) * 32 + l31];
+                        const float bv = *(const float*)(dimg + w * DRS + l31 * 4);
+                        dz = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, dz, 0, 0, 0);
+                    }
+                }
+                float sdz = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sdz += dz[r];
+                dbacc[k] += sdz;
+                // dW_k[co][ci] += sum_v dz[v][co] * x[v][ci]   (dz as the A operand, contraction in acc-row order)
+#pragma unroll
+                for (int it = 0; it < 2; ++it) {
+                    if (it < CIT) {
+                        if constexpr (BF) {
+#pragma unroll
+                            for (int s2 = 0; s2 < 2; ++s2) {
+                                i32x4 afr;
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) afr[j] = (int)pack_bf16x2(dz[8 * s2 + 2 * j], dz[8 * s2 + 2 * j + 1]);
+                                const int row0 = 16 * s2 + 4 * h + q4;
+                                const int col = (it * 32 + 16 * g1 + 4 * p4) * 2;
+                                const s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(ximg + row0 * XRS + col));
+                                const s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(ximg + (row0 + 8) * XRS + col));
+                                const s16x8 bfr = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+                                accw[k][it] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(s16x8, afr), bfr, accw[k][it], 0, 0, 0);
+                            }
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                const float bv = *(const float*)(ximg + acc_row(r, h) * XRS + (it * 32 + l31) * 4);
+                                accw[k][it] = __builtin_amdgcn_mfma_f32_32x32x2f32(dz[r], bv, accw[k][it], 0, 0, 0);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+
+    // reduce the 4 waves through LDS (one 32x32 tile at a time), then write this workgroup's partial
+    float* red = (float*)smem;                   // [4][16][64] floats = 16 KiB (images are free now)
+#pragma unroll
+    for (int k = 0; k < GCN_KMAX; ++k) {
+        if (k < K) {
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                if (it < CIT) {
+                    __syncthreads();
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = accw[k][it][r];
+                    __syncthreads();
+                    for (int e = tid; e < 16 * 64; e += 256) {
+                        const float s = red[e] + red[16 * 64 + e] + red[2 * 16 * 64 + e] + red[3 * 16 * 64 + e];
+                        const int r = e >> 6, ln = e & 63;
+                        const int co = c0 + acc_row(r, ln >> 5);
+                        const int ci = i0 + it * 32 + (ln & 31);
+                        if (co < Cout && ci < Cin && (it * 32 + (ln & 31)) < CIG)
+                            a.slabW[(((size_t)blockIdx.x * K + k) * Cout + co) * Cin + ci] = s;
+                    }
+                }
+            }
+            __syncthreads();
+            const float sb = dbacc[k] + __shfl_xor(dbacc[k], 32);
+            if (h == 0) red[wave * 32 + l31] = sb;
+            __syncthreads();
+            if (tid < 32 && blockIdx.z == 0 && c0 + tid < Cout)
+                a.slabB[((size_t)blockIdx.x * K + k) * Cout + c0 + tid] = red[tid] + red[32 + tid] + red[64 + tid] + red[96 + tid];
+        }
+    }
+}
+
+template <typename T>
+static int gcn_wgrad_run(GcnWgradArgs& a, float* dW, float* db, size_t ws_bytes, hipStream_t stream) {
+    constexpr int ES = ET<T>::ES, KSTEP = ET<T>::KSTEP;
+    if (a.Cin % KSTEP != 0 || a.Cin <= 0 || a.Cout % 8 != 0 || a.Cout <= 0 || a.K < 1 || a.K > GCN_KMAX || a.V < 1 || a.V > 32 || a.NF < 1) return STGCN_ERR_ARG;
+    const int cig = a.Cin >= 64 ? 64 : a.Cin;
+    if (a.Cin % cig != 0) return STGCN_ERR_ARG;
+    a.cig = cig;
+    const int drs = 32 * ES + 16, xrs = cig * ES + 16;
+    const size_t tabb = ET<T>::IS_BF16 ? (size_t)a.K * 2 * 64 * 16 : (size_t)a.K * 32 * 32 * 4;
+    size_t lds = (size_t)4 * (32 * drs + 32 * xrs) + tabb;
+    if (lds < 16 * 1024) lds = 16 * 1024;
+    const int ncot = ceil_div_i(a.Cout, 32), ncig = a.Cin / cig;
+    int gx = 768 / (ncot * ncig);
+    if (gx < 1) gx = 1;
+    const int fgroups = ceil_div_i(a.NF, 4);
+    if (gx > fgroups) gx = fgroups;
+    const size_t nW = (size_t)a.K * a.Cout * a.Cin, nB = (size_t)a.K * a.Cout;
+    while (gx > 1 && (size_t)gx * (nW + nB) * sizeof(float) > ws_bytes) gx /= 2;
+    if ((size_t)gx * (nW + nB) * sizeof(float) > ws_bytes) return STGCN_ERR_WORKSPACE;
+    a.iters = ceil_div_i(fgroups, gx);
+    a.slabB = a.slabW + (size_t)gx * nW;
+    auto kern = gcn_wgrad_kernel<T>;
+    static bool set = false;
+    if (!set) { if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return STGCN_ERR_LAUNCH; set = true; }
+    hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)ncot, (unsigned)ncig), dim3(256), lds, stream, a);
+    if (hipGetLastError() != hipSuccess) return STGCN_ERR_LAUNCH;
+    hipLaunchKernelGGL(sum_parts_kernel, dim3((unsigned)((nW + 255) / 256)), dim3(256), 0, stream, a.slabW, dW, gx, nW);
+    if (db) hipLaunchKernelGGL(sum_parts_kernel, dim3((unsigned)((nB + 255) / 256)), dim3(256), 0, stream, a.slabB, db, gx, nB);
+    return hipGetLastError() == hipSuccess ? STGCN_OK : STGCN_ERR_LAUNCH;
+}
+
+// dW is [K][Cout][Cin] f32 (the torch conv weight [K*Cout, Cin, 1, 1]); db is [K][Cout] or null.
+extern "C" int stgcn_gcn_wgrad(int dtype, const void* x, const void* dy, const float* adj, float* dW, float* db,
+                               int NF, int V, int Cin, int Cout, int K,
+                               void* workspace, size_t workspace_bytes, void* stream) {
+    if (!x || !dy || !adj || !dW || !workspace) return STGCN_ERR_ARG;
+    GcnWgradArgs a;
+    a.x = x; a.dy = dy; a.adj = adj; a.slabW = (float*)workspace; a.slabB = nullptr;
+    a.NF = NF; a.V = V; a.Cin = Cin; a.Cout = Cout; a.K = K; a.cig = 0; a.iters = 0;
+    if (dtype == STGCN_BF16) return gcn_wgrad_run<bf16>(a, dW, db, workspace_bytes, (hipStream_t)stream);
+    if (dtype == STGCN_F32) return gcn_wgrad_run<float>(a, dW, db, workspace_bytes, (hipStream_t)stream);
+    return STGCN_ERR_ARG;
+}

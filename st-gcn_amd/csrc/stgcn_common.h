@@ -1,0 +1,118 @@
+// Shared device helpers for the ST-GCN gfx950 kernels.
+//
+// Data layout used by every kernel in this library: activations are "channels-last",
+// physical [B][T][V][C] with C contiguous (a torch tensor of logical shape [B,C,T,V] in
+// torch.channels_last memory format).  Rows of the implicit GEMMs are the flattened
+// (t, v) positions of one sample; the contraction index (channels) is contiguous, which
+// is what the 32x32 MFMA operand fragments want: lane (r = lane&31, h = lane>>5) holds
+// 16 contiguous bytes of row r at byte offset 32*s + 16*h of k-step s.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define STGCN_OK 0
+#define STGCN_ERR_ARG 1
+#define STGCN_ERR_LAUNCH 2
+#define STGCN_ERR_WORKSPACE 3
+
+#define STGCN_F32 0
+#define STGCN_BF16 1
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+typedef __attribute__((ext_vector_type(2))) int i32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+
+struct bf16 { uint16_t v; };   // storage type tag for bf16 tensors
+
+template <typename T> struct ET;
+template <> struct ET<float> {
+    static constexpr int ES = 4;        // bytes per element
+    static constexpr int KSTEP = 8;     // elements per 32-byte k-step
+    static constexpr int VEC = 4;       // elements per 16 bytes
+    static constexpr bool IS_BF16 = false;
+};
+template <> struct ET<bf16> {
+    static constexpr int ES = 2;
+    static constexpr int KSTEP = 16;
+    static constexpr int VEC = 8;
+    static constexpr bool IS_BF16 = true;
+};
+
+__device__ __forceinline__ float bf16_bits_to_f32(uint32_t bits16) { return __uint_as_float(bits16 << 16); }
+
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    f32x2 v = {lo, hi};
+    bf16x2_t r = __builtin_convertvector(v, bf16x2_t);   // round-to-nearest-even, NaN stays NaN
+    return __builtin_bit_cast(uint32_t, r);
+}
+
+// 16 bytes of T <-> floats (VEC = 4 for f32, 8 for bf16)
+template <typename T> __device__ __forceinline__ void unpack16(const i32x4& raw, float* f) {
+    if constexpr (ET<T>::IS_BF16) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            uint32_t u = (uint32_t)raw[j];
+            f[2 * j] = __uint_as_float(u << 16);
+            f[2 * j + 1] = __uint_as_float(u & 0xFFFF0000u);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) f[j] = __int_as_float(raw[j]);
+    }
+}
+template <typename T> __device__ __forceinline__ i32x4 pack16(const float* f) {
+    i32x4 raw;
+    if constexpr (ET<T>::IS_BF16) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) raw[j] = (int)pack_bf16x2(f[2 * j], f[2 * j + 1]);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) raw[j] = __float_as_int(f[j]);
+    }
+    return raw;
+}
+
+template <typename T> __device__ __forceinline__ float load_elem(const T* p, size_t i) {
+    if constexpr (ET<T>::IS_BF16) return bf16_bits_to_f32(((const uint16_t*)p)[i]);
+    else return ((const float*)p)[i];
+}
+template <typename T> __device__ __forceinline__ void store_elem(T* p, size_t i, float v) {
+    if constexpr (ET<T>::IS_BF16) ((uint16_t*)p)[i] = (uint16_t)(pack_bf16x2(v, 0.f) & 0xFFFFu);
+    else ((float*)p)[i] = v;
+}
+
+// One 32-byte k-step of a 32x32 tile product: acc += A_frag * B_frag.
+//   bf16: one v_mfma_f32_32x32x16_bf16 (lane half h holds k = 8h..8h+7 of the step).
+//   f32 : four v_mfma_f32_32x32x2_f32; lane half h holds k = 4h..4h+3 of the 8-wide step
+//         and MFMA j contracts k = {j, 4+j}.  A and B use the same k permutation.
+template <typename T> __device__ __forceinline__ void mma_step(f32x16& acc, const i32x4& a, const i32x4& b) {
+    if constexpr (ET<T>::IS_BF16) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(s16x8, a), __builtin_bit_cast(s16x8, b), acc, 0, 0, 0);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__int_as_float(a[j]), __int_as_float(b[j]), acc, 0, 0, 0);
+    }
+}
+
+// Row of a 32x32 MFMA accumulator held in register r of lane half h.
+__device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// Dropout keep decision for the element at flat channels-last offset idx.
+__device__ __forceinline__ bool drop_keep(uint64_t idx, uint32_t seed, uint32_t thr) {
+    uint32_t x = (uint32_t)idx ^ seed;
+    x += (uint32_t)(idx >> 32) * 0x9E3779B9u;
+    x ^= x >> 16; x *= 0x7FEB352Du;
+    x ^= x >> 15; x *= 0x846CA68Bu;
+    x ^= x >> 16;
+    return x >= thr;
+}
+
+__device__ __forceinline__ i32x4 zero16() { i32x4 z = {0, 0, 0, 0}; return z; }
+
+static inline int ceil_div_i(int a, int b) { return (a + b - 1) / b; }

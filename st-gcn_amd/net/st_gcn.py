@@ -1,0 +1,147 @@
+"""ST-GCN model and block on hand-written gfx950 kernels.
+
+Drop-in for net.st_gcn of hensyou/st-gcn (st_gcn.py:9-197): Model(in_channels, num_class,
+graph_args, edge_importance_weighting, **kwargs), Model.forward(x[N,C,T,V,M]) -> [N,num_class],
+Model.extract_feature, st_gcn(in, out, kernel_size, stride, dropout, residual).forward(x, A)
+-> (y, A).  Sub-module names and parameter shapes equal the reference's, so checkpoints
+interchange; the nn.Conv2d / nn.BatchNorm2d / nn.Dropout sub-modules are parameter holders
+only.  Arithmetic runs in the HIP library through stgcn_rt; there is no CPU path.
+
+Extras over the reference signature (all optional): kwarg `compute_dtype` (torch.float32 or
+torch.bfloat16; default float32, or bfloat16 when env STGCN_DTYPE=bf16).
+"""
+import os
+
+import torch
+import torch.nn as nn
+
+from net.utils.graph import Graph
+from net.utils.tgcn import ConvTemporalGraphical
+from stgcn_rt import ops as P
+from stgcn_rt.functional import DataBnFn, HeadFn, StGcnBlockFn
+
+
+def _default_dtype():
+    v = os.environ.get("STGCN_DTYPE", "fp32").lower()
+    return torch.bfloat16 if v in ("bf16", "bfloat16") else torch.float32
+
+
+class Model(nn.Module):
+    def __init__(self, in_channels, num_class, graph_args, edge_importance_weighting, **kwargs):
+        super().__init__()
+        self.compute_dtype = kwargs.pop("compute_dtype", None) or _default_dtype()
+
+        self.graph = Graph(**graph_args)
+        A = torch.tensor(self.graph.A, dtype=torch.float32, requires_grad=False)
+        self.register_buffer("A", A)
+
+        K = A.size(0)
+        kernel_size = (9, K)
+        self.data_bn = nn.BatchNorm1d(in_channels * A.size(1))
+        first = {k: v for k, v in kwargs.items() if k != "dropout"}     # block 0 never drops (st_gcn.py:43-45)
+        plan = [(in_channels, 64, 1, dict(residual=False, **first)), (64, 64, 1, kwargs), (64, 64, 1, kwargs),
+                (64, 64, 1, kwargs), (64, 128, 2, kwargs), (128, 128, 1, kwargs), (128, 128, 1, kwargs),
+                (128, 256, 2, kwargs), (256, 256, 1, kwargs), (256, 256, 1, kwargs)]
+        self.st_gcn_networks = nn.ModuleList(st_gcn(ci, co, kernel_size, s, **kw) for ci, co, s, kw in plan)
+
+        if edge_importance_weighting:
+            self.edge_importance = nn.ParameterList(
+                [nn.Parameter(torch.ones(self.A.size())) for _ in self.st_gcn_networks])
+        else:
+            self.edge_importance = [1] * len(self.st_gcn_networks)
+
+        self.fcn = nn.Conv2d(256, num_class, kernel_size=1)
+
+    def _trunk(self, x):
+        N, C, T, V, M = x.size()
+        dtype = self.compute_dtype
+        bn = self.data_bn
+        h = DataBnFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, self.training, dtype,
+                           P.pad_to(C, P.kstep(dtype)))
+        if self.training:
+            bn.num_batches_tracked += 1
+        for gcn, importance in zip(self.st_gcn_networks, self.edge_importance):
+            h, _ = gcn(h, self.A * importance)
+        return h
+
+    def forward(self, x):
+        N, C, T, V, M = x.size()
+        h = self._trunk(x)
+        return HeadFn.apply(h, self.fcn.weight, self.fcn.bias, N, M)
+
+    def extract_feature(self, x):
+        """Inference only: per-position class scores [N,num_class,t,v,M] and features [N,256,t,v,M]."""
+        N, C, T, V, M = x.size()
+        with torch.no_grad():
+            h = self._trunk(x)
+            _, c, t, v = h.size()
+            feature = h.float().reshape(N, M, c, t, v).permute(0, 2, 3, 4, 1)
+            ncls = self.fcn.out_channels
+            o = P.conv_rows(P.cl(h), P.pack_conv_w(self.fcn.weight, h.dtype), ncls, t,
+                            bias=self.fcn.bias.float().contiguous(), ntaps=1)
+            output = o.float().reshape(N, M, ncls, t, v).permute(0, 2, 3, 4, 1)
+        return output, feature
+
+
+class st_gcn(nn.Module):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, dropout=0, residual=True):
+        super().__init__()
+        assert len(kernel_size) == 2
+        assert kernel_size[0] % 2 == 1
+        padding = ((kernel_size[0] - 1) // 2, 0)
+        self.in_channels, self.out_channels, self.stride = in_channels, out_channels, stride
+
+        self.gcn = ConvTemporalGraphical(in_channels, out_channels, kernel_size[1])
+        self.tcn = nn.Sequential(
+            nn.BatchNorm2d(out_channels),
+            nn.ReLU(inplace=True),
+            nn.Conv2d(out_channels, out_channels, (kernel_size[0], 1), (stride, 1), padding),
+            nn.BatchNorm2d(out_channels),
+            nn.Dropout(dropout, inplace=True),
+        )
+        if not residual:
+            self.residual_kind = "none"
+            self.residual = lambda x: 0
+        elif in_channels == out_channels and stride == 1:
+            self.residual_kind = "identity"
+            self.residual = lambda x: x
+        else:
+            self.residual_kind = "conv"
+            self.residual = nn.Sequential(
+                nn.Conv2d(in_channels, out_channels, kernel_size=1, stride=(stride, 1)),
+                nn.BatchNorm2d(out_channels),
+            )
+        self.relu = nn.ReLU(inplace=True)
+        self.compute_dtype = None
+        self._calls = 0
+
+    def _seed(self):
+        self._calls += 1
+        return (torch.initial_seed() * 0x9E3779B1 + self._calls * 0x85EBCA6B + id(self) % 65521) & 0xFFFFFFFF
+
+    def forward(self, x, A):
+        assert A.size(0) == self.gcn.kernel_size
+        dtype = self.compute_dtype or (x.dtype if x.dtype in (torch.float32, torch.bfloat16) else torch.float32)
+        cin = self.in_channels
+        cin_p = P.pad_to(cin, P.kstep(dtype))
+        if x.dtype != dtype:
+            x = x.to(dtype)
+        if x.size(1) != cin_p:
+            x = P.pad_channels(x, cin_p)
+        bn1, conv, bn2, drop = self.tcn[0], self.tcn[2], self.tcn[3], self.tcn[4]
+        if self.residual_kind == "conv":
+            rc, rb = self.residual[0], self.residual[1]
+            rargs = (rc.weight, rc.bias, rb.weight, rb.bias)
+            rbufs = (rb.running_mean, rb.running_var)
+        else:
+            rargs, rbufs = (None, None, None, None), (None, None)
+        cfg = (self.stride, self.residual_kind, self.training, float(drop.p), self._seed(), cin)
+        y = StGcnBlockFn.apply(x, A, self.gcn.conv.weight, self.gcn.conv.bias, bn1.weight, bn1.bias,
+                               conv.weight, conv.bias, bn2.weight, bn2.bias, *rargs,
+                               bn1.running_mean, bn1.running_var, bn2.running_mean, bn2.running_var, *rbufs, cfg)
+        if self.training:
+            bn1.num_batches_tracked += 1
+            bn2.num_batches_tracked += 1
+            if self.residual_kind == "conv":
+                self.residual[1].num_batches_tracked += 1
+        return y, A

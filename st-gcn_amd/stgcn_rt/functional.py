@@ -1,0 +1,232 @@
+"""autograd.Function wrappers: one per reference operator on the hot path.
+
+  GraphConvFn   ConvTemporalGraphical.forward        (net/utils/tgcn.py:57-66)
+  StGcnBlockFn  st_gcn.forward                       (net/st_gcn.py:191-197)
+  DataBnFn      Model.forward input normalisation    (net/st_gcn.py:72-78)
+  HeadFn        pooling + fcn                        (net/st_gcn.py:85-90)
+"""
+import torch
+
+from . import lib as L
+from . import ops as P
+
+
+def _act_dtype(dtype):
+    if dtype not in (torch.float32, torch.bfloat16):
+        raise TypeError("compute dtype must be float32 or bfloat16")
+    return dtype
+
+
+class GraphConvFn(torch.autograd.Function):
+    """y = einsum('nkctv,kvw->nctw', conv1x1(x).view(n,K,C,t,v), A); x already channel-padded."""
+
+    @staticmethod
+    def forward(ctx, x, A, W, b, cin_true):
+        P.check_act(x)
+        K, V = A.shape[0], A.shape[1]
+        dtype = x.dtype
+        cin_p = x.shape[1]
+        Cout = W.shape[0] // K
+        x = P.cl(x)
+        A32 = A.detach().to(torch.float32)
+        wp = P.pack_gcn_w(W.detach(), K, cin_p, dtype)
+        y = P.gcn_fused(x, wp, A32.transpose(1, 2).contiguous(), Cout, bias=None if b is None else b.detach().float().contiguous())
+        ctx.save_for_backward(x, A32, W, b if b is not None else torch.empty(0))
+        ctx.has_bias = b is not None
+        ctx.cin_true = cin_true
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, A32, W, b = ctx.saved_tensors
+        b = b if ctx.has_bias else None
+        K = A32.shape[0]
+        dtype = x.dtype
+        cin_p = x.shape[1]
+        Cout = W.shape[0] // K
+        dy = P.cl(dy.to(dtype))
+        bias = None if b is None else b.detach().float().contiguous()
+        dx = dA = dW = db = None
+        if ctx.needs_input_grad[0]:
+            wt = P.pack_gcn_wt(W.detach(), K, cin_p, dtype)
+            dx = P.gcn_fused(dy, wt, A32.contiguous(), cin_p)
+        if ctx.needs_input_grad[1]:
+            wp = P.pack_gcn_w(W.detach(), K, cin_p, dtype)
+            dA = P.gcn_agrad(x, wp, bias, dy)
+        if ctx.needs_input_grad[2] or (b is not None and ctx.needs_input_grad[3]):
+            dWp, db = P.gcn_wgrad(x, dy, A32.contiguous(), need_bias=b is not None)
+            dW = dWp[:, :, :ctx.cin_true].reshape(W.shape)
+        return dx, dA, dW, db, None
+
+
+class StGcnBlockFn(torch.autograd.Function):
+    """One st_gcn block.  Positional tensors:
+       x, A, Wg, bg, g1, b1, Wt, bt, g2, b2, Wr, br, gr, betar  (the last four None unless conv residual)
+       then running stats rm1, rv1, rm2, rv2, rmr, rvr (updated in place when training) and the config."""
+
+    @staticmethod
+    def forward(ctx, x, A, Wg, bg, g1, b1, Wt, bt, g2, b2, Wr, br, gr, betar,
+                rm1, rv1, rm2, rv2, rmr, rvr, cfg):
+        P.check_act(x)
+        stride, kind, training, drop_p, seed, cin_true = cfg
+        x = P.cl(x)
+        dtype = x.dtype
+        B, cin_p, T, V = x.shape
+        K = A.shape[0]
+        Cout = Wg.shape[0] // K
+        kt = Wt.shape[2]
+        pad = (kt - 1) // 2
+        To = (T + 2 * pad - (kt - 1) - 1) // stride + 1
+        dev = x.device
+        A32 = A.detach().to(torch.float32).contiguous()
+        f32 = lambda t: None if t is None else t.detach().float().contiguous()
+        stats = torch.zeros((3, 2 * Cout), dtype=torch.float64, device=dev) if training else None
+
+        wp = P.pack_gcn_w(Wg.detach(), K, cin_p, dtype)
+        y = P.gcn_fused(x, wp, A32.transpose(1, 2).contiguous(), Cout, bias=f32(bg), stats=stats[0] if training else None)
+        bn1 = P.bn_finalize(stats[0] if training else None, B * T * V, f32(g1), f32(b1), rm1, rv1, training)
+
+        wtp = P.pack_conv_w(Wt.detach(), dtype)
+        o = P.conv_rows(y, wtp, Cout, To, bias=f32(bt), pro=(bn1.scale, bn1.shift), stats=stats[1] if training else None,
+                        ntaps=kt, stride=stride, pad=pad)
+        bn2 = P.bn_finalize(stats[1] if training else None, B * To * V, f32(g2), f32(b2), rm2, rv2, training)
+
+        r, bnr = None, None
+        if kind == "conv":
+            wrp = P.pack_conv_w(Wr.detach(), dtype)
+            r = P.conv_rows(x, wrp, Cout, To, bias=f32(br), stats=stats[2] if training else None, ntaps=1, stride=stride, pad=0)
+            bnr = P.bn_finalize(stats[2] if training else None, B * To * V, f32(gr), f32(betar), rmr, rvr, training)
+            res = r
+        elif kind == "identity":
+            res = x
+        else:
+            res = None
+        p = drop_p if training else 0.0
+        out = P.block_out_fwd(o, res, bn2, bnr, p, seed)
+
+        ctx.cfg = (stride, kind, training, p, seed, cin_true, kt, pad)
+        ctx.bn = (bn1, bn2, bnr)
+        ctx.save_for_backward(x, A32, y, o, out, r if r is not None else torch.empty(0),
+                              Wg, bg, g1, Wt, g2, Wr if Wr is not None else torch.empty(0), gr if gr is not None else torch.empty(0))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, A32, y, o, out, r, Wg, bg, g1, Wt, g2, Wr, gr = ctx.saved_tensors
+        stride, kind, training, p, seed, cin_true, kt, pad = ctx.cfg
+        bn1, bn2, bnr = ctx.bn
+        dtype = x.dtype
+        B, cin_p, T, V = x.shape
+        K = A32.shape[0]
+        Cout = Wg.shape[0] // K
+        To = o.shape[2]
+        dev = x.device
+        dout = P.cl(dout.to(dtype))
+        f32 = lambda t: t.detach().float().contiguous()
+        r_ = r if kind == "conv" else None
+
+        dO, dR, g, stats2, statsr, dbo, dbr = P.block_out_bwd(
+            dout, out, o, r_, bn2, f32(g2), bnr, f32(gr) if kind == "conv" else None, kind == "identity", p, seed, training)
+        dg2, db2 = P.stats_to_grads(stats2, Cout)
+        dbt = dbo.float()
+
+        # temporal conv: weight grad (input = relu(bn1(y)) recomputed in the prologue), then data grad fused with
+        # the ReLU mask and the BN1-backward sums
+        dWt = P.conv_wgrad(y, dO, kt, stride, pad, pro=(bn1.scale, bn1.shift))
+        stats1 = torch.zeros((2 * Cout,), dtype=torch.float64, device=dev)
+        wtt = P.pack_conv_wt(Wt.detach(), dtype)
+        gh = P.conv_rows(dO, wtt, Cout, T, epilogue=L.EPI_RELU_BWD, aux=y, ep=(bn1.scale, bn1.shift, bn1.mean, bn1.rstd),
+                         stats=stats1, ntaps=kt, stride=stride, pad=pad, transposed=True)
+        dg1, db1 = P.stats_to_grads(stats1, Cout)
+        dy = P.bn_bwd_apply(gh, y, f32(g1), bn1, stats1, training, out=gh)
+
+        add = g
+        dWr = dbr_f = dgr = dbetar = None
+        if kind == "conv":
+            dgr, dbetar = P.stats_to_grads(statsr, Cout)
+            dbr_f = dbr.float()
+            dWr = P.conv_wgrad(x, dR, 1, stride, 0)
+            wrt = P.pack_conv_wt(Wr.detach(), dtype)
+            add = P.conv_rows(dR, wrt, cin_p, T, ntaps=1, stride=stride, pad=0, transposed=True)
+
+        wt = P.pack_gcn_wt(Wg.detach(), K, cin_p, dtype)
+        dx = P.gcn_fused(dy, wt, A32, cin_p, add=add)
+        dWp, dbg = P.gcn_wgrad(x, dy, A32, need_bias=True)
+        dWg = dWp[:, :, :cin_true].reshape(Wg.shape)
+        dA = None
+        if ctx.needs_input_grad[1]:
+            wp = P.pack_gcn_w(Wg.detach(), K, cin_p, dtype)
+            dA = P.gcn_agrad(x, wp, f32(bg), dy)
+        return (dx, dA, dWg, dbg, dg1, db1, dWt, dbt, dg2, db2, dWr, dbr_f, dgr, dbetar,
+                None, None, None, None, None, None, None)
+
+
+class DataBnFn(torch.autograd.Function):
+    """x [N,C,T,V,M] float32 -> channels-last activation [N*M, Cp, T, V] after BatchNorm1d(V*C)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, rmean, rvar, training, dtype, cp):
+        if not x.is_cuda:
+            raise RuntimeError("input must live on the GPU: the ST-GCN HIP path has no CPU fallback")
+        x = x.float().contiguous()
+        N, Cc, T, V, M = x.shape
+        dev = x.device
+        stats = None
+        if training:
+            stats = torch.zeros((2 * V * Cc,), dtype=torch.float64, device=dev)
+            L.call("stgcn_data_bn_stats", L.ptr(x), L.ptr(stats), N, Cc, T, V, M, L.stream_ptr())
+        bn = P.bn_finalize(stats, N * M * T, gamma.detach().float().contiguous(), beta.detach().float().contiguous(),
+                           rmean, rvar, training)
+        out = P.new_act(N * M, cp, T, V, dtype, dev)
+        L.call("stgcn_data_bn_apply", L.dtype_code(dtype), L.ptr(x), L.ptr(out), L.ptr(bn.scale), L.ptr(bn.shift),
+               N, Cc, T, V, M, cp, L.stream_ptr())
+        ctx.save_for_backward(x)
+        ctx.bn = bn
+        ctx.dims = (N, Cc, T, V, M, cp)
+        return out
+
+    @staticmethod
+    def backward(ctx, dx0):
+        (x,) = ctx.saved_tensors
+        N, Cc, T, V, M, cp = ctx.dims
+        dx0 = P.cl(dx0)
+        stats = torch.zeros((2 * V * Cc,), dtype=torch.float64, device=x.device)
+        L.call("stgcn_data_bn_bwd", L.dtype_code(dx0.dtype), L.ptr(dx0), L.ptr(x), L.ptr(ctx.bn.mean), L.ptr(ctx.bn.rstd), L.ptr(stats),
+               N, Cc, T, V, M, cp, L.stream_ptr())
+        dg, db = P.stats_to_grads(stats, V * Cc)
+        return None, dg, db, None, None, None, None, None
+
+
+class HeadFn(torch.autograd.Function):
+    """feat [N*M, C, T, V] -> logits [N, num_class]: avg-pool over (T,V), mean over M, 1x1 fcn."""
+
+    @staticmethod
+    def forward(ctx, feat, W, b, N, M):
+        P.check_act(feat)
+        feat = P.cl(feat)
+        Bc, Cc, T, V = feat.shape
+        ncls = W.shape[0]
+        dev = feat.device
+        pooled = torch.empty((Bc, Cc), dtype=torch.float32, device=dev)
+        L.call("stgcn_pool_fwd", L.dtype_code(feat.dtype), L.ptr(feat), L.ptr(pooled), Bc, T * V, Cc, L.stream_ptr())
+        Wf = W.detach().reshape(ncls, Cc).float().contiguous()
+        logits = torch.empty((N, ncls), dtype=torch.float32, device=dev)
+        L.call("stgcn_head_fc_fwd", L.ptr(pooled), L.ptr(Wf), L.ptr(b.detach().float().contiguous()), L.ptr(logits),
+               N, M, Cc, ncls, L.stream_ptr())
+        ctx.save_for_backward(pooled, Wf)
+        ctx.meta = (N, M, Cc, T, V, ncls, feat.dtype, W.shape)
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        pooled, Wf = ctx.saved_tensors
+        N, M, Cc, T, V, ncls, dtype, wshape = ctx.meta
+        dev = pooled.device
+        dlogits = dlogits.float().contiguous()
+        dW = torch.empty((ncls, Cc), dtype=torch.float32, device=dev)
+        db = torch.empty((ncls,), dtype=torch.float32, device=dev)
+        dpm = torch.empty((N, Cc), dtype=torch.float32, device=dev)
+        L.call("stgcn_head_fc_bwd", L.ptr(dlogits), L.ptr(pooled), L.ptr(Wf), L.ptr(dW), L.ptr(db), L.ptr(dpm), N, M, Cc, ncls, L.stream_ptr())
+        dfeat = P.new_act(N * M, Cc, T, V, dtype, dev)
+        L.call("stgcn_pool_bwd", L.dtype_code(dtype), L.ptr(dpm), L.ptr(dfeat), N * M, T * V, Cc, M, L.stream_ptr())
+        return dfeat, dW.reshape(wshape), db, None, None

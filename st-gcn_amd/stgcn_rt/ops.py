@@ -1,0 +1,227 @@
+"""Host side of the HIP path: torch tensors in, C-ABI kernel launches, torch tensors out.
+
+Activations are torch tensors of logical shape [B, C, T, V] in torch.channels_last memory
+format (physically [B][T][V][C]); parameters stay float32 in their reference shapes and are
+re-packed (tiny tensors) per call.  PyTorch here is plumbing: device memory, streams, autograd
+bookkeeping.  Every arithmetic step of the path is a kernel of libstgcn_hip.so.
+"""
+import torch
+
+from . import lib as L
+
+CL = torch.channels_last
+_ws = {}
+
+
+def kstep(dtype):
+    """Channel granularity of the MFMA kernels: one 32-byte k-step."""
+    return 16 if dtype == torch.bfloat16 else 8
+
+
+def kchunk(dtype):
+    """Channel granularity of conv_rows / conv_wgrad: one 128-byte chunk."""
+    return 64 if dtype == torch.bfloat16 else 32
+
+
+def pad_to(n, m):
+    return (n + m - 1) // m * m
+
+
+def workspace(device, nbytes=96 << 20):
+    key = (device.type, device.index)
+    w = _ws.get(key)
+    if w is None or w.numel() < nbytes:
+        w = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        _ws[key] = w
+    return w
+
+
+def cl(x):
+    return x.contiguous(memory_format=CL)
+
+
+def new_act(B, Cc, T, V, dtype, device):
+    return torch.empty((B, Cc, T, V), dtype=dtype, device=device, memory_format=CL)
+
+
+def check_act(x, name="x"):
+    if not x.is_cuda:
+        raise RuntimeError("%s must live on the GPU: the ST-GCN HIP path has no CPU fallback" % name)
+    if x.dim() != 4:
+        raise ValueError("%s must be [B, C, T, V]" % name)
+
+
+def pad_channels(x, cp):
+    """[B,C,T,V] -> [B,cp,T,V] channels-last, zero padded."""
+    B, Cc, T, V = x.shape
+    if Cc == cp:
+        return cl(x)
+    out = torch.zeros((B, cp, T, V), dtype=x.dtype, device=x.device, memory_format=CL)
+    out[:, :Cc] = x
+    return out
+
+
+# ----------------------------------------------------------------------------- weight packing
+def pack_gcn_w(W, K, cin_p, dtype):
+    """conv weight [K*Cout, Cin, 1, 1] -> [K][Cout][cin_p] (projection operand)."""
+    Cin = W.shape[1]
+    w = W.reshape(K, -1, Cin)
+    if cin_p != Cin:
+        w = torch.nn.functional.pad(w, (0, cin_p - Cin))
+    return w.to(dtype).contiguous()
+
+
+def pack_gcn_wt(W, K, cin_p, dtype):
+    """conv weight [K*Cout, Cin, 1, 1] -> [K][cin_p][Cout] (input-gradient operand)."""
+    Cin = W.shape[1]
+    w = W.reshape(K, -1, Cin).permute(0, 2, 1)
+    if cin_p != Cin:
+        w = torch.nn.functional.pad(w, (0, 0, 0, cin_p - Cin))
+    return w.to(dtype).contiguous()
+
+
+def pack_conv_w(W, dtype):
+    """conv weight [Cout, Cin, kt, 1] -> [kt][Cout][Cin]."""
+    return W[..., 0].permute(2, 0, 1).to(dtype).contiguous()
+
+
+def pack_conv_wt(W, dtype):
+    """conv weight [Cout, Cin, kt, 1] -> [kt][Cin][Cout] (transposed form)."""
+    return W[..., 0].permute(2, 1, 0).to(dtype).contiguous()
+
+
+# ----------------------------------------------------------------------------- kernel wrappers
+def conv_rows(x, w_packed, Cout, Tout, bias=None, pro=None, epilogue=L.EPI_PLAIN, aux=None, ep=None, stats=None,
+              ntaps=1, stride=1, pad=0, dil=1, transposed=False, out=None):
+    B, Cin, Tin, V = x.shape
+    if out is None:
+        out = new_act(B, Cout, Tout, V, x.dtype, x.device)
+    ps, pb = pro if pro is not None else (None, None)
+    es, eb, em, er = ep if ep is not None else (None, None, None, None)
+    L.call("stgcn_conv_rows", L.dtype_code(x.dtype), L.ptr(x), L.ptr(w_packed), L.ptr(out), L.ptr(bias), L.ptr(ps), L.ptr(pb),
+           epilogue, L.ptr(aux), L.ptr(es), L.ptr(eb), L.ptr(em), L.ptr(er), L.ptr(stats),
+           B, Tin, Tout, V, Cin, Cout, ntaps, stride, pad, dil, 1 if transposed else 0, L.stream_ptr())
+    return out
+
+
+def conv_wgrad(x, dout, ntaps, stride, pad, dil=1, pro=None):
+    """-> dW [Cout, Cin, ntaps, 1] float32."""
+    B, Cin, Tin, V = x.shape
+    Cout, Tout = dout.shape[1], dout.shape[2]
+    dW = torch.empty((Cout, Cin, ntaps, 1), dtype=torch.float32, device=x.device)
+    ws = workspace(x.device)
+    ps, pb = pro if pro is not None else (None, None)
+    L.call("stgcn_conv_wgrad", L.dtype_code(x.dtype), L.ptr(x), L.ptr(dout), L.ptr(dW), L.ptr(ps), L.ptr(pb),
+           B, Tin, Tout, V, Cin, Cout, ntaps, stride, pad, dil, L.ptr(ws), ws.numel(), L.stream_ptr())
+    return dW
+
+
+def gcn_fused(x, w_packed, adj, Nout, bias=None, add=None, stats=None):
+    """x [B,Cin,T,V] -> [B,Nout,T,V];  adj [K][a][b] float32 (out joint a, in joint b)."""
+    B, Cin, T, V = x.shape
+    K = adj.shape[0]
+    out = new_act(B, Nout, T, V, x.dtype, x.device)
+    L.call("stgcn_gcn_fused", L.dtype_code(x.dtype), L.ptr(x), L.ptr(w_packed), L.ptr(adj), L.ptr(bias), L.ptr(out), L.ptr(add),
+           L.ptr(stats), B * T, V, Cin, Nout, K, L.stream_ptr())
+    return out
+
+
+def _kgroups(K):
+    return [(k0, min(3, K - k0)) for k0 in range(0, K, 3)]
+
+
+def gcn_agrad(x, w_packed, bias, dy):
+    """-> dA_eff [K,V,V] float32.  w_packed [K][Cout][Cin_p]; bias [K*Cout] or None."""
+    B, Cin, T, V = x.shape
+    K, Cout = w_packed.shape[0], w_packed.shape[1]
+    dA = torch.empty((K, V, V), dtype=torch.float32, device=x.device)
+    ws = workspace(x.device)
+    for k0, kn in _kgroups(K):
+        bk = None if bias is None else bias[k0 * Cout:(k0 + kn) * Cout]
+        L.call("stgcn_gcn_agrad", L.dtype_code(x.dtype), L.ptr(x), L.ptr(w_packed[k0:k0 + kn]), L.ptr(bk), L.ptr(dy), L.ptr(dA[k0:k0 + kn]),
+               B * T, V, Cin, Cout, kn, L.ptr(ws), ws.numel(), L.stream_ptr())
+    return dA
+
+
+def gcn_wgrad(x, dy, adj, need_bias=True):
+    """-> dW [K,Cout,Cin_p] float32, db [K*Cout] float32.  adj = A_eff [K][v][w]."""
+    B, Cin, T, V = x.shape
+    Cout = dy.shape[1]
+    K = adj.shape[0]
+    dW = torch.empty((K, Cout, Cin), dtype=torch.float32, device=x.device)
+    db = torch.empty((K * Cout,), dtype=torch.float32, device=x.device) if need_bias else None
+    ws = workspace(x.device)
+    for k0, kn in _kgroups(K):
+        dbk = None if db is None else db[k0 * Cout:(k0 + kn) * Cout]
+        L.call("stgcn_gcn_wgrad", L.dtype_code(x.dtype), L.ptr(x), L.ptr(dy), L.ptr(adj[k0:k0 + kn]), L.ptr(dW[k0:k0 + kn]), L.ptr(dbk),
+               B * T, V, Cin, Cout, kn, L.ptr(ws), ws.numel(), L.stream_ptr())
+    return dW, db
+
+
+class BnParams:
+    """mean / rstd / scale / shift of one BatchNorm evaluation (float32 [C] each)."""
+    __slots__ = ("mean", "rstd", "scale", "shift")
+
+    def __init__(self, Cc, device):
+        buf = torch.empty((4, Cc), dtype=torch.float32, device=device)
+        self.mean, self.rstd, self.scale, self.shift = buf[0], buf[1], buf[2], buf[3]
+
+
+def bn_finalize(stats, count, gamma, beta, rmean, rvar, training, momentum=0.1, eps=1e-5):
+    Cc = gamma.numel()
+    bp = BnParams(Cc, gamma.device)
+    L.call("stgcn_bn_finalize", L.ptr(stats), float(count), L.ptr(gamma), L.ptr(beta), L.ptr(rmean), L.ptr(rvar),
+           float(momentum), float(eps), L.ptr(bp.mean), L.ptr(bp.rstd), L.ptr(bp.scale), L.ptr(bp.shift), Cc, 1 if training else 0,
+           L.stream_ptr())
+    return bp
+
+
+def stats_to_grads(stats, Cc):
+    dg = torch.empty((Cc,), dtype=torch.float32, device=stats.device)
+    dbt = torch.empty((Cc,), dtype=torch.float32, device=stats.device)
+    L.call("stgcn_stats_to_grads", L.ptr(stats), L.ptr(dg), L.ptr(dbt), Cc, L.stream_ptr())
+    return dg, dbt
+
+
+def block_out_fwd(o, res, bn2, bnr, drop_p, seed):
+    B, Cc, T, V = o.shape
+    out = new_act(B, Cc, T, V, o.dtype, o.device)
+    L.call("stgcn_block_out_fwd", L.dtype_code(o.dtype), L.ptr(o), L.ptr(res), L.ptr(out), L.ptr(bn2.scale), L.ptr(bn2.shift),
+           L.ptr(bnr.scale) if bnr is not None else None, L.ptr(bnr.shift) if bnr is not None else None,
+           B * T * V, Cc, float(drop_p), int(seed) & 0xFFFFFFFF, L.stream_ptr())
+    return out
+
+
+def block_out_bwd(dout, out, o, r, bn2, gamma2, bnr, gammar, want_g, drop_p, seed, training):
+    """-> dO, dR (or None), g (or None), stats2 [2,C] (sum gd, sum gd*ohat), statsr, dbias_o, dbias_r (double)."""
+    B, Cc, T, V = o.shape
+    rows = B * T * V
+    acc = torch.zeros((6, Cc), dtype=torch.float64, device=o.device)
+    stats2, statsr, dbo, dbr = acc[0:2], acc[2:4], acc[4], acc[5]
+    has_r = r is not None
+    args = [L.dtype_code(o.dtype), 0, L.ptr(dout), L.ptr(out), L.ptr(o), L.ptr(r), L.ptr(bn2.mean), L.ptr(bn2.rstd), L.ptr(gamma2),
+            L.ptr(bnr.mean) if has_r else None, L.ptr(bnr.rstd) if has_r else None, L.ptr(gammar) if has_r else None,
+            L.ptr(stats2), L.ptr(statsr) if has_r else None, None, None, None, L.ptr(dbo), L.ptr(dbr) if has_r else None,
+            rows, Cc, float(drop_p), int(seed) & 0xFFFFFFFF, float(rows), 1 if training else 0, L.stream_ptr()]
+    L.call("stgcn_block_out_bwd", *args)
+    dO = new_act(B, Cc, T, V, o.dtype, o.device)
+    dR = new_act(B, Cc, T, V, o.dtype, o.device) if has_r else None
+    g = new_act(B, Cc, T, V, o.dtype, o.device) if want_g else None
+    args[1] = 1
+    args[14], args[15], args[16] = L.ptr(dO), L.ptr(dR), L.ptr(g)
+    L.call("stgcn_block_out_bwd", *args)
+    return dO, dR, g, stats2, (statsr if has_r else None), dbo, (dbr if has_r else None)
+
+
+def bn_bwd_apply(g, y, gamma, bn, stats, training, out=None):
+    B, Cc, T, V = y.shape
+    if out is None:
+        out = new_act(B, Cc, T, V, y.dtype, y.device)
+    L.call("stgcn_bn_bwd_apply", L.dtype_code(y.dtype), L.ptr(g), L.ptr(y), L.ptr(out), L.ptr(gamma), L.ptr(bn.mean), L.ptr(bn.rstd),
+           L.ptr(stats), float(B * T * V), B * T * V, Cc, 1 if training else 0, L.stream_ptr())
+    return out
+
+
+def sgd_step(params, grads, mom, lr, momentum, weight_decay, nesterov, first_step, grad_scale=1.0):
+    L.call("stgcn_sgd_step", L.ptr(params), L.ptr(grads), L.ptr(mom), params.numel(), float(lr), float(momentum), float(weight_decay),
+           1 if nesterov else 0, 1 if first_step else 0, float(grad_scale), L.stream_ptr())

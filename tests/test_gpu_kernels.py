@@ -1,0 +1,295 @@
+"""GPU parity tests of the individual HIP kernels, called through the C-ABI, against the CPU
+oracle on the same seeded inputs.  Tolerances (max-abs error relative to the max-abs of the
+oracle result): float32 1e-4, bfloat16 2e-2 -- the bars the task states."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import stgcn_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+TOL = {torch.float32: 1e-4, torch.bfloat16: 2e-2}
+DTYPES = [torch.float32, torch.bfloat16]
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def rt():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a GPU (run with -m gpu on the MI355X box)")
+    from stgcn_rt import lib, ops
+    lib.load()
+    return ops
+
+
+def t64(shape, tag, lo=-1.0, hi=1.0):
+    return torch.tensor(O.det_uniform(shape, tag, lo, hi), dtype=torch.float64)
+
+
+def to_dev(x, dtype):
+    """[B,C,T,V] float64 CPU -> channels-last device tensor."""
+    return x.to(DEV).to(dtype).contiguous(memory_format=torch.channels_last)
+
+
+def q(x, dtype):
+    """What the kernel actually sees: the oracle input rounded to the storage dtype."""
+    return x.to(dtype).to(torch.float64)
+
+
+def rel(a, b):
+    a = a.detach().to("cpu", torch.float64)
+    b = b.detach().to("cpu", torch.float64)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return ((a - b).abs().max() / (b.abs().max() + 1e-30)).item()
+
+
+def test_probe_tr16(rt):
+    from stgcn_rt import lib as L
+    out = torch.zeros(64 * 8, dtype=torch.int16, device=DEV)
+    L.call("stgcn_probe_tr16", out.data_ptr(), L.stream_ptr())
+    got = out.cpu().numpy().reshape(64, 8)
+    for lane in range(64):
+        h, col = lane >> 5, lane & 31
+        exp = [((8 * h + j) << 8) | col for j in range(8)]
+        assert list(got[lane]) == exp, (lane, list(got[lane]), exp)
+
+
+CONV_CASES = [
+    # B, Cin, Cout, T, V, ntaps, stride, pad, prologue
+    (2, 64, 64, 20, 25, 9, 1, 4, True),
+    (1, 128, 128, 37, 25, 9, 2, 4, True),
+    (2, 64, 128, 19, 18, 1, 2, 0, False),
+    (1, 128, 64, 12, 18, 9, 1, 4, False),
+    (1, 256, 60, 6, 25, 1, 1, 0, False),
+    (1, 64, 64, 300, 25, 9, 1, 4, True),
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_conv_rows_forward(rt, case, dtype):
+    B, Cin, Cout, T, V, kt, stride, pad, pro = case
+    x = q(t64((B, Cin, T, V), 11), dtype)
+    W = q(t64((Cout, Cin, kt), 12) * (1.5 / np.sqrt(Cin * kt)), dtype)
+    b = t64((Cout,), 13, -0.2, 0.2)
+    sc, sh = t64((Cin,), 14, 0.5, 1.5), t64((Cin,), 15, -0.3, 0.3)
+    h = torch.clamp_min(x * sc[None, :, None, None] + sh[None, :, None, None], 0) if pro else x
+    if pro and dtype == torch.bfloat16:
+        h = q(h, dtype)                       # the kernel rounds the activated input before the MFMA
+    ref = O.tconv_forward(h, W, b, stride, pad)
+    To = ref.shape[2]
+    stats = torch.zeros(2 * Cout, dtype=torch.float64, device=DEV)
+    wp = rt.pack_conv_w(W[..., None].to(DEV).float(), dtype)
+    out = rt.conv_rows(to_dev(x, dtype), wp, Cout, To, bias=b.to(DEV).float(),
+                       pro=(sc.to(DEV).float(), sh.to(DEV).float()) if pro else None, stats=stats,
+                       ntaps=kt, stride=stride, pad=pad)
+    torch.cuda.synchronize()
+    assert out.shape == ref.shape
+    assert rel(out, ref) < TOL[dtype]
+    s = stats.cpu()
+    n = B * To * V
+    assert rel(s[:Cout] / n, ref.mean(dim=(0, 2, 3))) < TOL[dtype] * 2 + 1e-6
+    assert rel(s[Cout:] / n, (ref ** 2).mean(dim=(0, 2, 3))) < TOL[dtype] * 2
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("case", CONV_CASES[:4], ids=lambda c: "x".join(map(str, c)))
+def test_conv_rows_transposed_and_wgrad(rt, case, dtype):
+    B, Cin, Cout, T, V, kt, stride, pad, pro = case
+    x = q(t64((B, Cin, T, V), 21), dtype)
+    W = q(t64((Cout, Cin, kt), 22) * (1.5 / np.sqrt(Cin * kt)), dtype)
+    sc, sh = t64((Cin,), 24, 0.5, 1.5), t64((Cin,), 25, -0.3, 0.3)
+    h = torch.clamp_min(x * sc[None, :, None, None] + sh[None, :, None, None], 0) if pro else x
+    if pro and dtype == torch.bfloat16:
+        h = q(h, dtype)
+    To = O.tconv_out_len(T, kt, stride, pad)
+    do = q(t64((B, Cout, To, V), 23), dtype)
+    dh, dW, _ = O.tconv_backward(h, W, do, stride, pad)
+    # data gradient through the transposed form
+    wt = rt.pack_conv_wt(W[..., None].to(DEV).float(), dtype)
+    got = rt.conv_rows(to_dev(do, dtype), wt, Cin, T, ntaps=kt, stride=stride, pad=pad, transposed=True)
+    assert rel(got, dh) < TOL[dtype]
+    # weight gradient
+    gW = rt.conv_wgrad(to_dev(x, dtype), to_dev(do, dtype), kt, stride, pad,
+                       pro=(sc.to(DEV).float(), sh.to(DEV).float()) if pro else None)
+    assert rel(gW[..., 0], dW) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+def test_conv_rows_relu_bwd_epilogue(rt, dtype):
+    from stgcn_rt import lib as L
+    B, Cc, T, V, kt = 2, 64, 21, 25, 9
+    y = q(t64((B, Cc, T, V), 31), dtype)
+    do = q(t64((B, Cc, T, V), 32), dtype)
+    W = q(t64((Cc, Cc, kt), 33) * 0.05, dtype)
+    gamma, beta = t64((Cc,), 34, 0.8, 1.2), t64((Cc,), 35, -0.2, 0.2)
+    mean = y.mean(dim=(0, 2, 3))
+    rstd = 1.0 / torch.sqrt(y.var(dim=(0, 2, 3), unbiased=False) + 1e-5)
+    scale, shift = gamma * rstd, beta - mean * gamma * rstd
+    sh4 = lambda v: v[None, :, None, None]
+    pre = y * sh4(scale) + sh4(shift)
+    dh, _, _ = O.tconv_backward(torch.clamp_min(pre, 0), W, do, 1, 4)
+    g = dh * (pre > 0)
+    xhat = (y - sh4(mean)) * sh4(rstd)
+    stats = torch.zeros(2 * Cc, dtype=torch.float64, device=DEV)
+    f = lambda v: v.to(DEV).float().contiguous()
+    got = rt.conv_rows(to_dev(do, dtype), rt.pack_conv_wt(W[..., None].to(DEV).float(), dtype), Cc, T,
+                       epilogue=L.EPI_RELU_BWD, aux=to_dev(y, dtype), ep=(f(scale), f(shift), f(mean), f(rstd)),
+                       stats=stats, ntaps=kt, stride=1, pad=4, transposed=True)
+    assert rel(got, g) < TOL[dtype]
+    s = stats.cpu()
+    assert rel(s[:Cc], g.sum(dim=(0, 2, 3))) < TOL[dtype] * 3
+    assert rel(s[Cc:], (g * xhat).sum(dim=(0, 2, 3))) < TOL[dtype] * 3
+
+
+GCN_DIRECT = [
+    # layout, strategy, dense, B, Cin, Cout, T
+    ("ntu-rgb+d", "spatial", False, 2, 64, 64, 12),
+    ("ntu-rgb+d", "spatial", True, 1, 64, 128, 10),
+    ("openpose", "spatial", True, 2, 128, 128, 9),
+    ("openpose", "uniform", False, 2, 16, 64, 11),
+    ("ntu-rgb+d", "distance", True, 1, 256, 256, 5),
+    ("ntu-rgb+d", "spatial", True, 1, 128, 256, 7),
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("case", GCN_DIRECT, ids=lambda c: "-".join(map(str, c)))
+def test_gcn_kernels(rt, case, dtype):
+    lay, strat, dense, B, Cin, Cout, T = case
+    A0 = O.build_graph(lay, strat)["A"]
+    K, V = A0.shape[0], A0.shape[1]
+    A = t64(A0.shape, 41, -0.5, 0.5) if dense else torch.tensor(A0) * t64(A0.shape, 41, 0.5, 1.5)
+    x = q(t64((B, Cin, T, V), 42), dtype)
+    W = q(t64((K * Cout, Cin), 43) * (1.5 / np.sqrt(Cin)), dtype)
+    b = t64((K * Cout,), 44, -0.2, 0.2)
+    dy = q(t64((B, Cout, T, V), 45), dtype)
+    Aq = q(A, dtype)                     # the kernels feed A to the MFMA in the storage dtype
+    y = O.gcn_forward(x, Aq, W, b)
+    dx, dW, db, dA = O.gcn_backward(x, Aq, W, b, dy)
+
+    Ad = A.to(DEV).float()
+    W4 = W.reshape(K * Cout, Cin, 1, 1).to(DEV).float()
+    bd = b.to(DEV).float()
+    xd, dyd = to_dev(x, dtype), to_dev(dy, dtype)
+    stats = torch.zeros(2 * Cout, dtype=torch.float64, device=DEV)
+    yk = rt.gcn_fused(xd, rt.pack_gcn_w(W4, K, Cin, dtype), Ad.transpose(1, 2).contiguous(), Cout, bias=bd, stats=stats)
+    tol = TOL[dtype]
+    assert rel(yk, y) < tol
+    n = B * T * V
+    assert rel(stats.cpu()[:Cout] / n, y.mean(dim=(0, 2, 3))) < 2 * tol + 1e-6
+    assert rel(stats.cpu()[Cout:] / n, (y ** 2).mean(dim=(0, 2, 3))) < 2 * tol
+    dxk = rt.gcn_fused(dyd, rt.pack_gcn_wt(W4, K, Cin, dtype), Ad.contiguous(), Cin)
+    assert rel(dxk, dx) < tol
+    dWk, dbk = rt.gcn_wgrad(xd, dyd, Ad.contiguous())
+    assert rel(dWk.reshape(K * Cout, Cin), dW) < tol
+    assert rel(dbk, db) < tol
+    # dA: the projected activations are rounded to the storage dtype inside the kernel (bf16 only)
+    dAk = rt.gcn_agrad(xd, rt.pack_gcn_w(W4, K, Cin, dtype), bd, dyd)
+    assert rel(dAk, dA) < tol
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("Cc,rows_shape", [(64, (2, 20, 25)), (128, (1, 19, 18)), (256, (2, 5, 25))])
+def test_block_out_and_bn_kernels(rt, Cc, rows_shape, dtype):
+    B, T, V = rows_shape
+    o = q(t64((B, Cc, T, V), 51), dtype)
+    res = q(t64((B, Cc, T, V), 52), dtype)
+    r = q(t64((B, Cc, T, V), 53), dtype)
+    dout = q(t64((B, Cc, T, V), 54), dtype)
+    g2, b2 = t64((Cc,), 55, 0.8, 1.2), t64((Cc,), 56, -0.2, 0.2)
+    gr, br = t64((Cc,), 57, 0.8, 1.2), t64((Cc,), 58, -0.2, 0.2)
+    rows = B * T * V
+    f = lambda v: v.to(DEV).float().contiguous()
+    sh4 = lambda v: v[None, :, None, None]
+    zeros = torch.zeros(Cc, dtype=torch.float64)
+    ones = torch.ones(Cc, dtype=torch.float64)
+
+    def stats_of(t):
+        s = torch.cat([t.sum(dim=(0, 2, 3)), (t ** 2).sum(dim=(0, 2, 3))]).to(DEV)
+        return s
+
+    for kind, p in (("identity", 0.0), ("conv", 0.0), ("none", 0.0), ("identity", 0.5)):
+        seed = 1234
+        bn2 = rt.bn_finalize(stats_of(o), rows, f(g2), f(b2), f(zeros), f(ones), True)
+        q2, c2, _ = O.bn_forward(o, g2, b2, zeros, ones, True)
+        keep, ks = None, 1.0
+        if p > 0:
+            keep = torch.tensor(O.dropout_keep_mask(o.numel(), seed, p).reshape(B, T, V, Cc)).permute(0, 3, 1, 2)
+            ks = 1.0 / (1 - p)
+            q2 = q2 * keep * ks
+        bnr = None
+        if kind == "identity":
+            s = q2 + res
+            resd = to_dev(res, dtype)
+        elif kind == "conv":
+            bnr = rt.bn_finalize(stats_of(r), rows, f(gr), f(br), f(zeros), f(ones), True)
+            rb, cr, _ = O.bn_forward(r, gr, br, zeros, ones, True)
+            s = q2 + rb
+            resd = to_dev(r, dtype)
+        else:
+            s = q2
+            resd = None
+        out_ref = torch.clamp_min(s, 0)
+        out = rt.block_out_fwd(to_dev(o, dtype), resd, bn2, bnr, p, seed)
+        tol = TOL[dtype]
+        assert rel(out, out_ref) < tol, (kind, p)
+
+        # backward, evaluated at the kernel's own output so the ReLU mask is identical
+        outq = out.detach().to("cpu", torch.float64)
+        ds = dout * (outq > 0)
+        dq = ds if keep is None else ds * keep * ks
+        do_ref, dg2_ref, db2_ref = O.bn_backward(o, g2, c2, dq, True)
+        dO, dR, g, stats2, statsr, dbo, dbr = rt.block_out_bwd(
+            to_dev(dout, dtype), out, to_dev(o, dtype), to_dev(r, dtype) if kind == "conv" else None,
+            bn2, f(g2), bnr, f(gr) if kind == "conv" else None, kind == "identity", p, seed, True)
+        assert rel(dO, do_ref) < tol * 2, (kind, p)
+        assert rel(stats2.cpu()[1], dg2_ref) < tol * 2 and rel(stats2.cpu()[0], db2_ref) < tol * 2
+        if kind == "identity":
+            assert rel(g, ds) < tol
+        if kind == "conv":
+            dr_ref, dgr_ref, dbr_ref = O.bn_backward(r, gr, cr, ds, True)
+            assert rel(dR, dr_ref) < tol * 2
+            assert rel(statsr.cpu()[1], dgr_ref) < tol * 2
+
+    # BN1 backward apply
+    y = o
+    gin = dout
+    _, c1, _ = O.bn_forward(y, g2, b2, zeros, ones, True)
+    dy_ref, dg_ref, db_ref = O.bn_backward(y, g2, c1, gin, True)
+    bn1 = rt.bn_finalize(stats_of(y), rows, f(g2), f(b2), f(zeros), f(ones), True)
+    sums = torch.cat([db_ref, dg_ref]).to(DEV)
+    dy = rt.bn_bwd_apply(to_dev(gin, dtype), to_dev(y, dtype), f(g2), bn1, sums, True)
+    assert rel(dy, dy_ref) < TOL[dtype] * 2
+
+
+def test_bn_finalize_running_stats(rt):
+    Cc, n = 64, 1000
+    x = t64((n, Cc), 61) * 3 + 0.5
+    stats = torch.cat([x.sum(0), (x ** 2).sum(0)]).to(DEV)
+    rm, rv = t64((Cc,), 62, -0.1, 0.1), t64((Cc,), 63, 0.5, 1.5)
+    g, b = t64((Cc,), 64, 0.8, 1.2), t64((Cc,), 65, -0.1, 0.1)
+    rmd, rvd = rm.to(DEV).float(), rv.to(DEV).float()
+    bn = rt.bn_finalize(stats, n, g.to(DEV).float(), b.to(DEV).float(), rmd, rvd, True)
+    _, (mean, rstd), (nrm, nrv) = O.bn_forward(x, g, b, rm, rv, True)
+    assert rel(bn.mean, mean) < 1e-5 and rel(bn.rstd, rstd) < 1e-5
+    assert rel(rmd, nrm) < 1e-5 and rel(rvd, nrv) < 1e-5
+    assert rel(bn.scale, g * rstd) < 1e-5 and rel(bn.shift, b - mean * g * rstd) < 1e-4
+    bn_e = rt.bn_finalize(None, n, g.to(DEV).float(), b.to(DEV).float(), rmd, rvd, False)
+    assert rel(bn_e.mean, nrm) < 1e-6
+
+
+def test_sgd_kernel(rt):
+    n = 100003
+    p, g, m = t64((n,), 71), t64((n,), 72), t64((n,), 73)
+    pd, gd, md = p.to(DEV).float(), g.to(DEV).float(), m.to(DEV).float()
+    rt.sgd_step(pd, gd, md, 0.1, 0.9, 1e-4, True, False)
+    prm, grd, mom = {"w": p.clone()}, {"w": g}, {"w": m.clone()}
+    O.sgd_nesterov_step(prm, grd, mom, 0.1)
+    assert rel(pd, prm["w"]) < 1e-6 and rel(md, mom["w"]) < 1e-6
+    pd2, md2 = p.to(DEV).float(), torch.zeros(n, device=DEV)
+    rt.sgd_step(pd2, gd, md2, 0.1, 0.9, 1e-4, True, True)
+    prm, mom = {"w": p.clone()}, {}
+    O.sgd_nesterov_step(prm, grd, mom, 0.1)
+    assert rel(pd2, prm["w"]) < 1e-6 and rel(md2, mom["w"]) < 1e-6

@@ -332,11 +332,16 @@ def block_residual_kind(cin, cout, stride, residual=True):
     return "conv"
 
 
-def block_forward(x, A, p, bufs, stride, residual_kind, training, keep=None, keep_scale=1.0):
+def block_forward(x, A, p, bufs, stride, residual_kind, training, keep=None, keep_scale=1.0,
+                  h_mask=None, out_mask=None):
     """One st_gcn block.  p: dict of parameters (reference state-dict names, block-relative,
     conv weights in their 4-D torch shapes).  bufs: dict of running stats ('tcn.0.running_mean' ...).
     keep: optional dropout keep-mask [B,C,T',V] (1/0); output is scaled by keep_scale=1/(1-p).
-    Returns out, cache, new_bufs.
+    h_mask / out_mask: optional boolean tensors that REPLACE the two ReLU decisions (inner ReLU after
+    the first BatchNorm, final ReLU).  A reduced-precision implementation decides elements whose
+    pre-activation is within its rounding error of zero differently from float64; forcing its
+    decisions makes forward and backward comparable element by element (the functions are then
+    smooth in everything else).  Returns out, cache, new_bufs.
     """
     K = A.shape[0]
     Wg = p["gcn.conv.weight"].reshape(p["gcn.conv.weight"].shape[0], -1)
@@ -344,14 +349,15 @@ def block_forward(x, A, p, bufs, stride, residual_kind, training, keep=None, kee
     nb = {}
     h1, c1, (nb["tcn.0.running_mean"], nb["tcn.0.running_var"]) = bn_forward(
         y, p["tcn.0.weight"], p["tcn.0.bias"], bufs["tcn.0.running_mean"], bufs["tcn.0.running_var"], training)
-    h = torch.clamp_min(h1, 0)
+    hmask = (h1 > 0) if h_mask is None else h_mask
+    h = h1 * hmask.to(h1.dtype)
     Wt = p["tcn.2.weight"][..., 0]                           # [C,C,9]
     o = tconv_forward(h, Wt, p["tcn.2.bias"], stride)
     q, c2, (nb["tcn.3.running_mean"], nb["tcn.3.running_var"]) = bn_forward(
         o, p["tcn.3.weight"], p["tcn.3.bias"], bufs["tcn.3.running_mean"], bufs["tcn.3.running_var"], training)
     if keep is not None:
         q = q * keep * keep_scale
-    cache = dict(x=x, A=A, y=y, h1=h1, o=o, c1=c1, c2=c2, keep=keep, keep_scale=keep_scale)
+    cache = dict(x=x, A=A, y=y, h1=h1, h=h, hmask=hmask, o=o, c1=c1, c2=c2, keep=keep, keep_scale=keep_scale)
     if residual_kind == "identity":
         s = q + x
     elif residual_kind == "conv":
@@ -364,22 +370,23 @@ def block_forward(x, A, p, bufs, stride, residual_kind, training, keep=None, kee
         s = q + rb
     else:
         s = q
-    out = torch.clamp_min(s, 0)
-    cache["out"] = out
+    omask = (s > 0) if out_mask is None else out_mask
+    out = s * omask.to(s.dtype)
+    cache["out"], cache["omask"] = out, omask
     return out, cache, nb
 
 
 def block_backward(dout, p, cache, stride, residual_kind, training):
     """Returns dx, dA, grads (dict with the same names as p)."""
     g = {}
-    ds = dout * (cache["out"] > 0).to(dout.dtype)
+    ds = dout * cache["omask"].to(dout.dtype)
     dq = ds if cache["keep"] is None else ds * cache["keep"] * cache["keep_scale"]
     do, g["tcn.3.weight"], g["tcn.3.bias"] = bn_backward(cache["o"], p["tcn.3.weight"], cache["c2"], dq, training)
-    h = torch.clamp_min(cache["h1"], 0)
+    h = cache["h"]
     Wt = p["tcn.2.weight"][..., 0]
     dh, dWt, g["tcn.2.bias"] = tconv_backward(h, Wt, do, stride)
     g["tcn.2.weight"] = dWt[..., None]
-    dh1 = dh * (cache["h1"] > 0).to(dh.dtype)
+    dh1 = dh * cache["hmask"].to(dh.dtype)
     dy, g["tcn.0.weight"], g["tcn.0.bias"] = bn_backward(cache["y"], p["tcn.0.weight"], cache["c1"], dh1, training)
     Wg = p["gcn.conv.weight"].reshape(p["gcn.conv.weight"].shape[0], -1)
     dx, dWg, g["gcn.conv.bias"], dA = gcn_backward(cache["x"], cache["A"], Wg, p["gcn.conv.bias"], dy)
@@ -481,10 +488,11 @@ def _block_view(sd, i):
     return p, b
 
 
-def model_forward(sd, x, training, dropout=0.0, seeds=None, return_feature=False):
+def model_forward(sd, x, training, dropout=0.0, seeds=None, return_feature=False, masks=None):
     """x [N,C,T,V,M] -> logits [N,num_class].  sd: full state dict (reference names).
     Returns logits, cache, new_buffers (dict of updated running stats, full names).
     seeds: per-block dropout seeds (blocks 1..9 use dropout when training and dropout>0).
+    masks: optional {block index: (h_mask, out_mask)} forwarded to block_forward.
     """
     N, C, T, V, M = x.shape
     A = sd["A"]
@@ -508,7 +516,8 @@ def model_forward(sd, x, training, dropout=0.0, seeds=None, return_feature=False
             m = dropout_keep_mask(N * M * cout * To * V, seeds[i], dropout).reshape(N * M, To, V, cout)
             keep = torch.tensor(m, dtype=h.dtype).permute(0, 3, 1, 2)
             scale = 1.0 / (1.0 - dropout)
-        h, cache, nb = block_forward(h, Ai, p, b, stride, kind, training, keep, scale)
+        hm, om = masks[i] if masks is not None and i in masks else (None, None)
+        h, cache, nb = block_forward(h, Ai, p, b, stride, kind, training, keep, scale, hm, om)
         cache["kind"], cache["stride"] = kind, stride
         caches.append(cache)
         for k, v in nb.items():

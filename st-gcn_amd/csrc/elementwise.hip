@@ -169,7 +169,8 @@ extern "C" int stgcn_block_out_fwd(int dtype, const void* o, const void* res, vo
 //   stats2 = [sum gd, sum gd*ohat]  (ohat = (o - mean2) * rstd2)
 //   statsr = [sum g,  sum g*rhat]   (only for the conv residual: rhat = (r - meanr) * rstdr)
 struct BlockOutBwdArgs {
-    const void* dout; const void* out; const void* o; const void* r;
+    const void* dout; const float* dpool; size_t rows_per_sample;
+    const void* out; const void* o; const void* r;
     const float* mean2; const float* rstd2; const float* gamma2;
     const float* meanr; const float* rstdr; const float* gammar;
     double* stats2; double* statsr;
@@ -177,6 +178,23 @@ struct BlockOutBwdArgs {
     double* dbias_o; double* dbias_r;
     size_t rows; int C; uint32_t seed, thr; float keep_scale; double count; int training;
 };
+
+// incoming gradient of the block output: a stored tensor, and/or a per-(sample, channel) value that is
+// constant over (t, v) -- the gradient of the global average pool that follows the last block
+template <typename T>
+__device__ __forceinline__ void load_dout(const BlockOutBwdArgs& a, size_t row, size_t off, int cv, float* d) {
+    constexpr int VEC = ET<T>::VEC;
+    if (a.dout) unpack16<T>(*(const i32x4*)((const T*)a.dout + off), d);
+    else {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) d[j] = 0.f;
+    }
+    if (a.dpool) {
+        const float* p = a.dpool + (row / a.rows_per_sample) * a.C + cv * VEC;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) d[j] += p[j];
+    }
+}
 
 template <typename T>
 __global__ __launch_bounds__(256) void block_out_bwd_reduce_kernel(BlockOutBwdArgs a) {
@@ -198,7 +216,7 @@ __global__ __launch_bounds__(256) void block_out_bwd_reduce_kernel(BlockOutBwdAr
         for (size_t row = (size_t)blockIdx.x * m.rpi + m.rl; row < a.rows; row += (size_t)gridDim.x * m.rpi) {
             const size_t off = row * a.C + m.cv * VEC;
             float d[VEC], y[VEC], o[VEC], r[VEC];
-            unpack16<T>(*(const i32x4*)((const T*)a.dout + off), d);
+            load_dout<T>(a, row, off, m.cv, d);
             unpack16<T>(*(const i32x4*)((const T*)a.out + off), y);
             unpack16<T>(*(const i32x4*)((const T*)a.o + off), o);
             if (a.r) unpack16<T>(*(const i32x4*)((const T*)a.r + off), r);
@@ -248,7 +266,7 @@ __global__ __launch_bounds__(256) void block_out_bwd_apply_kernel(BlockOutBwdArg
         for (size_t row = (size_t)blockIdx.x * m.rpi + m.rl; row < a.rows; row += (size_t)gridDim.x * m.rpi) {
             const size_t off = row * a.C + m.cv * VEC;
             float d[VEC], y[VEC], o[VEC], r[VEC], gg[VEC], dr[VEC];
-            unpack16<T>(*(const i32x4*)((const T*)a.dout + off), d);
+            load_dout<T>(a, row, off, m.cv, d);
             unpack16<T>(*(const i32x4*)((const T*)a.out + off), y);
             unpack16<T>(*(const i32x4*)((const T*)a.o + off), o);
             if (a.dR) unpack16<T>(*(const i32x4*)((const T*)a.r + off), r);
@@ -276,16 +294,18 @@ __global__ __launch_bounds__(256) void block_out_bwd_apply_kernel(BlockOutBwdArg
     block_channel_reduce<T, 2>(sums, m, a.C, dst);
 }
 
-extern "C" int stgcn_block_out_bwd(int dtype, int pass, const void* dout, const void* out, const void* o, const void* r,
+extern "C" int stgcn_block_out_bwd(int dtype, int pass, const void* dout, const float* dpool, size_t rows_per_sample,
+                                   const void* out, const void* o, const void* r,
                                    const float* mean2, const float* rstd2, const float* gamma2,
                                    const float* meanr, const float* rstdr, const float* gammar,
                                    double* stats2, double* statsr, void* dO, void* dR, void* g,
                                    double* dbias_o, double* dbias_r,
                                    size_t rows, int C, float drop_p, uint32_t seed, double count, int training, void* stream) {
-    if (!dout || !out || !o || !mean2 || !rstd2 || !stats2) return STGCN_ERR_ARG;
+    if ((!dout && !dpool) || !out || !o || !mean2 || !rstd2 || !stats2) return STGCN_ERR_ARG;
+    if (dpool && rows_per_sample == 0) return STGCN_ERR_ARG;
     if (r && (!meanr || !rstdr || !statsr)) return STGCN_ERR_ARG;
     BlockOutBwdArgs a;
-    a.dout = dout; a.out = out; a.o = o; a.r = r; a.mean2 = mean2; a.rstd2 = rstd2; a.gamma2 = gamma2;
+    a.dout = dout; a.dpool = dpool; a.rows_per_sample = rows_per_sample; a.out = out; a.o = o; a.r = r; a.mean2 = mean2; a.rstd2 = rstd2; a.gamma2 = gamma2;
     a.meanr = meanr; a.rstdr = rstdr; a.gammar = gammar; a.stats2 = stats2; a.statsr = statsr;
     a.dO = dO; a.dR = dR; a.g = g; a.dbias_o = dbias_o; a.dbias_r = dbias_r;
     a.rows = rows; a.C = C; a.seed = seed; a.thr = drop_thr(drop_p); a.keep_scale = 1.f / (1.f - drop_p);

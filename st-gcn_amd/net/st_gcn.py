@@ -52,7 +52,7 @@ class Model(nn.Module):
 
         self.fcn = nn.Conv2d(256, num_class, kernel_size=1)
 
-    def _trunk(self, x):
+    def _trunk(self, x, pool_last=False):
         N, C, T, V, M = x.size()
         dtype = self.compute_dtype
         bn = self.data_bn
@@ -60,14 +60,18 @@ class Model(nn.Module):
                            P.pad_to(C, P.kstep(dtype)))
         if self.training:
             bn.num_batches_tracked += 1
-        for gcn, importance in zip(self.st_gcn_networks, self.edge_importance):
+        last = len(self.st_gcn_networks) - 1
+        for i, (gcn, importance) in enumerate(zip(self.st_gcn_networks, self.edge_importance)):
+            if pool_last and i == last:
+                # global average pool over (T, V) fused into the last block (st_gcn.py:85 of the reference)
+                return gcn.forward_pooled(h, self.A * importance)[1]
             h, _ = gcn(h, self.A * importance)
         return h
 
     def forward(self, x):
         N, C, T, V, M = x.size()
-        h = self._trunk(x)
-        return HeadFn.apply(h, self.fcn.weight, self.fcn.bias, N, M)
+        pooled = self._trunk(x, pool_last=True)
+        return HeadFn.apply(pooled, self.fcn.weight, self.fcn.bias, N, M)
 
     def extract_feature(self, x):
         """Inference only: per-position class scores [N,num_class,t,v,M] and features [N,256,t,v,M]."""
@@ -120,6 +124,13 @@ class st_gcn(nn.Module):
         return (torch.initial_seed() * 0x9E3779B1 + self._calls * 0x85EBCA6B + id(self) % 65521) & 0xFFFFFFFF
 
     def forward(self, x, A):
+        return self._run(x, A, False)[0], A
+
+    def forward_pooled(self, x, A):
+        """-> (y, mean of y over (T, V) as float32 [B, C])."""
+        return self._run(x, A, True)
+
+    def _run(self, x, A, want_pool):
         assert A.size(0) == self.gcn.kernel_size
         dtype = self.compute_dtype or (x.dtype if x.dtype in (torch.float32, torch.bfloat16) else torch.float32)
         cin = self.in_channels
@@ -135,8 +146,8 @@ class st_gcn(nn.Module):
             rbufs = (rb.running_mean, rb.running_var)
         else:
             rargs, rbufs = (None, None, None, None), (None, None)
-        cfg = (self.stride, self.residual_kind, self.training, float(drop.p), self._seed(), cin)
-        y = StGcnBlockFn.apply(x, A, self.gcn.conv.weight, self.gcn.conv.bias, bn1.weight, bn1.bias,
+        cfg = (self.stride, self.residual_kind, self.training, float(drop.p), self._seed(), cin, want_pool)
+        y, pooled = StGcnBlockFn.apply(x, A, self.gcn.conv.weight, self.gcn.conv.bias, bn1.weight, bn1.bias,
                                conv.weight, conv.bias, bn2.weight, bn2.bias, *rargs,
                                bn1.running_mean, bn1.running_var, bn2.running_mean, bn2.running_var, *rbufs, cfg)
         if self.training:
@@ -144,4 +155,4 @@ class st_gcn(nn.Module):
             bn2.num_batches_tracked += 1
             if self.residual_kind == "conv":
                 self.residual[1].num_batches_tracked += 1
-        return y, A
+        return y, pooled

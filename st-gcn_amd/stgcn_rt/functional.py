@@ -11,6 +11,11 @@ from . import lib as L
 from . import ops as P
 
 
+# Test hook: when set to a list, every StGcnBlockFn.backward appends the two ReLU decisions it used
+# (inner ReLU after BN1, final ReLU) so a checker can evaluate its reference with the same decisions.
+CAPTURE = None
+
+
 def _act_dtype(dtype):
     if dtype not in (torch.float32, torch.bfloat16):
         raise TypeError("compute dtype must be float32 or bfloat16")
@@ -44,18 +49,28 @@ class GraphConvFn(torch.autograd.Function):
         dtype = x.dtype
         cin_p = x.shape[1]
         Cout = W.shape[0] // K
-        dy = P.cl(dy.to(dtype))
-        bias = None if b is None else b.detach().float().contiguous()
+        cout_p = P.pad_to(Cout, P.kstep(dtype))          # the gradient kernels contract over whole k-steps
+        dy = P.pad_channels(dy.to(dtype), cout_p)
+        Wd = W.detach()
+        bias = None if b is None else b.detach().float()
+        if cout_p != Cout:
+            Wd = torch.nn.functional.pad(Wd.reshape(K, Cout, -1), (0, 0, 0, cout_p - Cout)).reshape(K * cout_p, -1, 1, 1)
+            if bias is not None:
+                bias = torch.nn.functional.pad(bias.reshape(K, Cout), (0, cout_p - Cout)).reshape(-1)
+        if bias is not None:
+            bias = bias.contiguous()
         dx = dA = dW = db = None
         if ctx.needs_input_grad[0]:
-            wt = P.pack_gcn_wt(W.detach(), K, cin_p, dtype)
+            wt = P.pack_gcn_wt(Wd, K, cin_p, dtype)
             dx = P.gcn_fused(dy, wt, A32.contiguous(), cin_p)
         if ctx.needs_input_grad[1]:
-            wp = P.pack_gcn_w(W.detach(), K, cin_p, dtype)
+            wp = P.pack_gcn_w(Wd, K, cin_p, dtype)
             dA = P.gcn_agrad(x, wp, bias, dy)
         if ctx.needs_input_grad[2] or (b is not None and ctx.needs_input_grad[3]):
-            dWp, db = P.gcn_wgrad(x, dy, A32.contiguous(), need_bias=b is not None)
-            dW = dWp[:, :, :ctx.cin_true].reshape(W.shape)
+            dWp, dbp = P.gcn_wgrad(x, dy, A32.contiguous(), need_bias=b is not None)
+            dW = dWp[:, :Cout, :ctx.cin_true].reshape(W.shape)
+            if dbp is not None:
+                db = dbp.reshape(K, cout_p)[:, :Cout].reshape(-1)
         return dx, dA, dW, db, None
 
 
@@ -68,7 +83,8 @@ class StGcnBlockFn(torch.autograd.Function):
     def forward(ctx, x, A, Wg, bg, g1, b1, Wt, bt, g2, b2, Wr, br, gr, betar,
                 rm1, rv1, rm2, rv2, rmr, rvr, cfg):
         P.check_act(x)
-        stride, kind, training, drop_p, seed, cin_true = cfg
+        stride, kind, training, drop_p, seed, cin_true, want_pool = cfg
+        ctx.set_materialize_grads(False)
         x = P.cl(x)
         dtype = x.dtype
         B, cin_p, T, V = x.shape
@@ -104,14 +120,18 @@ class StGcnBlockFn(torch.autograd.Function):
         p = drop_p if training else 0.0
         out = P.block_out_fwd(o, res, bn2, bnr, p, seed)
 
+        pooled = None
+        if want_pool:                                   # mean over (T, V) of the block output, float32 [B, C]
+            pooled = torch.empty((B, Cout), dtype=torch.float32, device=dev)
+            L.call("stgcn_pool_fwd", L.dtype_code(dtype), L.ptr(out), L.ptr(pooled), B, To * V, Cout, L.stream_ptr())
         ctx.cfg = (stride, kind, training, p, seed, cin_true, kt, pad)
         ctx.bn = (bn1, bn2, bnr)
         ctx.save_for_backward(x, A32, y, o, out, r if r is not None else torch.empty(0),
                               Wg, bg, g1, Wt, g2, Wr if Wr is not None else torch.empty(0), gr if gr is not None else torch.empty(0))
-        return out
+        return out, pooled
 
     @staticmethod
-    def backward(ctx, dout):
+    def backward(ctx, dout, dpooled):
         x, A32, y, o, out, r, Wg, bg, g1, Wt, g2, Wr, gr = ctx.saved_tensors
         stride, kind, training, p, seed, cin_true, kt, pad = ctx.cfg
         bn1, bn2, bnr = ctx.bn
@@ -121,12 +141,19 @@ class StGcnBlockFn(torch.autograd.Function):
         Cout = Wg.shape[0] // K
         To = o.shape[2]
         dev = x.device
-        dout = P.cl(dout.to(dtype))
+        if dout is None and dpooled is None:
+            return (None,) * 21
+        if dout is not None:
+            dout = P.cl(dout.to(dtype))
+        dpool = None
+        if dpooled is not None:                         # d(mean over T*V): constant over (t, v), kept in float32
+            dpool = (dpooled.float() / float(To * V)).contiguous()
         f32 = lambda t: t.detach().float().contiguous()
         r_ = r if kind == "conv" else None
 
         dO, dR, g, stats2, statsr, dbo, dbr = P.block_out_bwd(
-            dout, out, o, r_, bn2, f32(g2), bnr, f32(gr) if kind == "conv" else None, kind == "identity", p, seed, training)
+            dout, out, o, r_, bn2, f32(g2), bnr, f32(gr) if kind == "conv" else None, kind == "identity", p, seed, training,
+            dpool=dpool)
         dg2, db2 = P.stats_to_grads(stats2, Cout)
         dbt = dbo.float()
 
@@ -138,6 +165,10 @@ class StGcnBlockFn(torch.autograd.Function):
         gh = P.conv_rows(dO, wtt, Cout, T, epilogue=L.EPI_RELU_BWD, aux=y, ep=(bn1.scale, bn1.shift, bn1.mean, bn1.rstd),
                          stats=stats1, ntaps=kt, stride=stride, pad=pad, transposed=True)
         dg1, db1 = P.stats_to_grads(stats1, Cout)
+        if CAPTURE is not None:
+            pre = y.float() * bn1.scale[None, :, None, None] + bn1.shift[None, :, None, None]
+            near = pre.abs() < 1e-4          # decided by the kernel's own fma there: read it off its output
+            CAPTURE.append(dict(h_mask=torch.where(near, gh != 0, pre > 0), out_mask=(out > 0)))
         dy = P.bn_bwd_apply(gh, y, f32(g1), bn1, stats1, training, out=gh)
 
         add = g
@@ -198,35 +229,34 @@ class DataBnFn(torch.autograd.Function):
 
 
 class HeadFn(torch.autograd.Function):
-    """feat [N*M, C, T, V] -> logits [N, num_class]: avg-pool over (T,V), mean over M, 1x1 fcn."""
+    """pooled [N*M, C] float32 (mean over (T,V) of the last block) -> logits [N, num_class]:
+    mean over the M persons, then the 1x1 fcn."""
 
     @staticmethod
-    def forward(ctx, feat, W, b, N, M):
-        P.check_act(feat)
-        feat = P.cl(feat)
-        Bc, Cc, T, V = feat.shape
+    def forward(ctx, pooled, W, b, N, M):
+        if not pooled.is_cuda:
+            raise RuntimeError("input must live on the GPU: the ST-GCN HIP path has no CPU fallback")
+        pooled = pooled.float().contiguous()
+        Bc, Cc = pooled.shape
         ncls = W.shape[0]
-        dev = feat.device
-        pooled = torch.empty((Bc, Cc), dtype=torch.float32, device=dev)
-        L.call("stgcn_pool_fwd", L.dtype_code(feat.dtype), L.ptr(feat), L.ptr(pooled), Bc, T * V, Cc, L.stream_ptr())
+        dev = pooled.device
         Wf = W.detach().reshape(ncls, Cc).float().contiguous()
         logits = torch.empty((N, ncls), dtype=torch.float32, device=dev)
         L.call("stgcn_head_fc_fwd", L.ptr(pooled), L.ptr(Wf), L.ptr(b.detach().float().contiguous()), L.ptr(logits),
                N, M, Cc, ncls, L.stream_ptr())
         ctx.save_for_backward(pooled, Wf)
-        ctx.meta = (N, M, Cc, T, V, ncls, feat.dtype, W.shape)
+        ctx.meta = (N, M, Cc, ncls, W.shape)
         return logits
 
     @staticmethod
     def backward(ctx, dlogits):
         pooled, Wf = ctx.saved_tensors
-        N, M, Cc, T, V, ncls, dtype, wshape = ctx.meta
+        N, M, Cc, ncls, wshape = ctx.meta
         dev = pooled.device
         dlogits = dlogits.float().contiguous()
         dW = torch.empty((ncls, Cc), dtype=torch.float32, device=dev)
         db = torch.empty((ncls,), dtype=torch.float32, device=dev)
         dpm = torch.empty((N, Cc), dtype=torch.float32, device=dev)
         L.call("stgcn_head_fc_bwd", L.ptr(dlogits), L.ptr(pooled), L.ptr(Wf), L.ptr(dW), L.ptr(db), L.ptr(dpm), N, M, Cc, ncls, L.stream_ptr())
-        dfeat = P.new_act(N * M, Cc, T, V, dtype, dev)
-        L.call("stgcn_pool_bwd", L.dtype_code(dtype), L.ptr(dpm), L.ptr(dfeat), N * M, T * V, Cc, M, L.stream_ptr())
-        return dfeat, dW.reshape(wshape), db, None, None
+        dpooled = (dpm / float(M)).repeat_interleave(M, dim=0)      # [N*M, C]: every person gets 1/M of its clip's gradient
+        return dpooled, dW.reshape(wshape), db, None, None

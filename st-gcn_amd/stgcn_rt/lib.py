@@ -28,7 +28,7 @@ _SIGS = {
     "stgcn_bn_finalize": [_vp, _d, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _i, _i, _vp],
     "stgcn_stats_to_grads": [_vp, _vp, _vp, _i, _vp],
     "stgcn_block_out_fwd": [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _f, _u32, _vp],
-    "stgcn_block_out_bwd": [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+    "stgcn_block_out_bwd": [_i, _i, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                             _vp, _vp, _sz, _i, _f, _u32, _d, _i, _vp],
     "stgcn_bn_bwd_apply": [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _d, _sz, _i, _i, _vp],
     "stgcn_data_bn_stats": [_vp, _vp, _i, _i, _i, _i, _i, _vp],
@@ -91,7 +91,12 @@ def dtype_code(dt):
     raise TypeError("stgcn kernels take float32 or bfloat16 activations, got %s" % dt)
 
 
+_SYNC = os.environ.get("STGCN_SYNC", "0") == "1"     # debugging aid: synchronise after every launch
+
+
 def call(name, *args):
     rc = getattr(load(), name)(*args)
+    if _SYNC:
+        torch.cuda.synchronize()
     if rc != 0:
         raise RuntimeError("%s failed: %s (status %d)" % (name, _ERR.get(rc, "?"), rc))

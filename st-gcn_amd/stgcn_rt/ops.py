@@ -56,7 +56,7 @@ def pad_channels(x, cp):
     B, Cc, T, V = x.shape
     if Cc == cp:
         return cl(x)
-    out = torch.zeros((B, cp, T, V), dtype=x.dtype, device=x.device, memory_format=CL)
+    out = torch.empty((B, cp, T, V), dtype=x.dtype, device=x.device, memory_format=CL).zero_()
     out[:, :Cc] = x
     return out
 
@@ -192,14 +192,15 @@ def block_out_fwd(o, res, bn2, bnr, drop_p, seed):
     return out
 
 
-def block_out_bwd(dout, out, o, r, bn2, gamma2, bnr, gammar, want_g, drop_p, seed, training):
-    """-> dO, dR (or None), g (or None), stats2 [2,C] (sum gd, sum gd*ohat), statsr, dbias_o, dbias_r (double)."""
+def block_out_bwd(dout, out, o, r, bn2, gamma2, bnr, gammar, want_g, drop_p, seed, training, dpool=None):
+    """-> dO, dR (or None), g (or None), stats2 [2,C] (sum gd, sum gd*ohat), statsr, dbias_o, dbias_r (double).
+    The incoming gradient is dout (stored tensor) and/or dpool [B,C] float32, constant over (t,v)."""
     B, Cc, T, V = o.shape
     rows = B * T * V
     acc = torch.zeros((6, Cc), dtype=torch.float64, device=o.device)
     stats2, statsr, dbo, dbr = acc[0:2], acc[2:4], acc[4], acc[5]
     has_r = r is not None
-    args = [L.dtype_code(o.dtype), 0, L.ptr(dout), L.ptr(out), L.ptr(o), L.ptr(r), L.ptr(bn2.mean), L.ptr(bn2.rstd), L.ptr(gamma2),
+    args = [L.dtype_code(o.dtype), 0, L.ptr(dout), L.ptr(dpool), T * V, L.ptr(out), L.ptr(o), L.ptr(r), L.ptr(bn2.mean), L.ptr(bn2.rstd), L.ptr(gamma2),
             L.ptr(bnr.mean) if has_r else None, L.ptr(bnr.rstd) if has_r else None, L.ptr(gammar) if has_r else None,
             L.ptr(stats2), L.ptr(statsr) if has_r else None, None, None, None, L.ptr(dbo), L.ptr(dbr) if has_r else None,
             rows, Cc, float(drop_p), int(seed) & 0xFFFFFFFF, float(rows), 1 if training else 0, L.stream_ptr()]
@@ -208,7 +209,7 @@ def block_out_bwd(dout, out, o, r, bn2, gamma2, bnr, gammar, want_g, drop_p, see
     dR = new_act(B, Cc, T, V, o.dtype, o.device) if has_r else None
     g = new_act(B, Cc, T, V, o.dtype, o.device) if want_g else None
     args[1] = 1
-    args[14], args[15], args[16] = L.ptr(dO), L.ptr(dR), L.ptr(g)
+    args[16], args[17], args[18] = L.ptr(dO), L.ptr(dR), L.ptr(g)
     L.call("stgcn_block_out_bwd", *args)
     return dO, dR, g, stats2, (statsr if has_r else None), dbo, (dbr if has_r else None)
 

@@ -63,6 +63,8 @@ CONV_CASES = [
     (1, 128, 64, 12, 18, 9, 1, 4, False),
     (1, 256, 60, 6, 25, 1, 1, 0, False),
     (1, 64, 64, 300, 25, 9, 1, 4, True),
+    (4, 128, 256, 12, 25, 1, 2, 0, False),
+    (4, 256, 256, 6, 25, 9, 1, 4, True),
 ]
 
 
@@ -94,7 +96,7 @@ def test_conv_rows_forward(rt, case, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
-@pytest.mark.parametrize("case", CONV_CASES[:4], ids=lambda c: "x".join(map(str, c)))
+@pytest.mark.parametrize("case", CONV_CASES[:4] + CONV_CASES[6:], ids=lambda c: "x".join(map(str, c)))
 def test_conv_rows_transposed_and_wgrad(rt, case, dtype):
     B, Cin, Cout, T, V, kt, stride, pad, pro = case
     x = q(t64((B, Cin, T, V), 21), dtype)
@@ -151,6 +153,8 @@ GCN_DIRECT = [
     ("openpose", "uniform", False, 2, 16, 64, 11),
     ("ntu-rgb+d", "distance", True, 1, 256, 256, 5),
     ("ntu-rgb+d", "spatial", True, 1, 128, 256, 7),
+    ("ntu-rgb+d", "spatial", False, 4, 128, 256, 12),
+    ("ntu-rgb+d", "spatial", False, 4, 256, 256, 6),
 ]
 
 
@@ -293,3 +297,24 @@ def test_sgd_kernel(rt):
     prm, mom = {"w": p.clone()}, {}
     O.sgd_nesterov_step(prm, grd, mom, 0.1)
     assert rel(pd2, prm["w"]) < 1e-6 and rel(md2, mom["w"]) < 1e-6
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+def test_block_out_bwd_pooled_gradient(rt, dtype):
+    """The pooled-gradient form (a float32 [B,C] vector, constant over (t,v)) equals the stored-tensor form."""
+    B, Cc, T, V = 3, 128, 7, 25
+    o = q(t64((B, Cc, T, V), 81), dtype)
+    out = torch.clamp_min(q(t64((B, Cc, T, V), 82), dtype), 0)
+    dp = t64((B, Cc), 83)
+    g2 = t64((Cc,), 84, 0.8, 1.2)
+    f = lambda v: v.to(DEV).float().contiguous()
+    stats = torch.cat([o.sum(dim=(0, 2, 3)), (o ** 2).sum(dim=(0, 2, 3))]).to(DEV)
+    bn2 = rt.bn_finalize(stats, B * T * V, f(g2), f(torch.zeros(Cc)), f(torch.zeros(Cc)), f(torch.ones(Cc)), True)
+    dense = dp[:, :, None, None].expand(B, Cc, T, V)
+    _, c2, _ = O.bn_forward(o, g2, torch.zeros(Cc, dtype=torch.float64), torch.zeros(Cc, dtype=torch.float64), torch.ones(Cc, dtype=torch.float64), True)
+    do_ref, dg_ref, db_ref = O.bn_backward(o, g2, c2, dense * (out > 0), True)
+    dO, _, _, stats2, _, _, _ = rt.block_out_bwd(None, to_dev(out, dtype), to_dev(o, dtype), None, bn2, f(g2), None, None,
+                                                 False, 0.0, 1, True, dpool=f(dp))
+    tol = TOL[dtype]
+    assert rel(dO, do_ref) < tol * 2
+    assert rel(stats2.cpu()[1], dg_ref) < tol * 2 and rel(stats2.cpu()[0], db_ref) < tol * 2

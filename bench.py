@@ -1,0 +1,220 @@
+#!/usr/bin/env python
+"""Benchmark of the ST-GCN training hot path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W [--dtype bf16|fp32] [--batch 64]
+
+One "step" = REC_Processor.train's iteration (forward, mean cross-entropy, backward, gradient
+all-reduce when N > 1, SGD-nesterov update) on synthetic NTU-RGB+D tensors already resident in
+HBM: x [64, 3, 300, 25, 2] per GPU (weak scaling), 60 classes, dropout 0.5, lr 0.1, momentum 0.9,
+weight decay 1e-4 (config/st_gcn/ntu-xsub/train.yaml of the reference).  Rank 0 prints ONE JSON
+line.  `roofline` prices the kernel that takes the most time, with the launch durations measured by
+events on the launch stream inside the timed region; `cpu_baseline` times the CPU oracle (a port of
+the same step) on the host cores, rank 0 at N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "st-gcn_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import torch
+import torch.distributed as dist
+
+PEAK = {"bf16": 2500.0, "fp32": 157.3}      # dense MFMA TFLOP/s (MI355X)
+HBM_PEAK = 8000.0                           # GB/s
+
+
+def kernel_work(key):
+    """Algorithmic FLOPs and compulsory bytes of one launch, from the timing key of stgcn_rt.ops."""
+    name = key[0]
+    es = 2 if "bfloat16" in str(key[1]) else 4
+    if name == "stgcn_conv_rows":
+        _, dt, tr, epi, B, Tin, Tout, V, Cin, Cout, ntaps, stride, pro = key
+        rows_small = min(Tin, Tout) * V * B                    # every tap is applied once per low-rate row
+        flops = 2.0 * Cin * Cout * ntaps * rows_small
+        byts = (B * Tin * V * Cin + B * Tout * V * Cout) * es + ntaps * Cin * Cout * es
+        if epi == 1:
+            byts += B * Tout * V * Cout * es                   # the BN input re-read by the fused ReLU/BN backward
+        return flops, byts, "mfma"
+    if name == "stgcn_conv_wgrad":
+        _, dt, B, Tin, Tout, V, Cin, Cout, ntaps, stride = key
+        return 2.0 * Cin * Cout * ntaps * B * Tout * V, (B * Tin * V * Cin + B * Tout * V * Cout) * es + 4 * ntaps * Cin * Cout, "mfma"
+    if name == "stgcn_gcn_fused":
+        _, dt, NF, V, Cin, Nout, K, add = key
+        return 2.0 * K * NF * V * (Cin * Nout + Nout * V), NF * V * (Cin + Nout * (2 if add else 1)) * es + K * Cin * Nout * es, "mfma"
+    if name in ("stgcn_gcn_wgrad", "stgcn_gcn_agrad"):
+        _, dt, NF, V, Cin, Cout, K = key
+        return 2.0 * K * NF * V * (Cin * Cout + Cout * V), NF * V * (Cin + Cout) * es, "mfma"
+    if name == "stgcn_block_out_fwd":
+        _, dt, rows, C, has_res, _ = key
+        return 0.0, rows * C * es * (3 if has_res else 2), "hbm"
+    if name == "stgcn_block_out_bwd":
+        rows, C, has_r = key[3], key[4], key[5]
+        p = key[2]
+        n = (4 if has_r else 3) + (0 if p == 0 else (2 if has_r else 1) + (1 if len(key) > 6 and key[6] else 0))
+        return 0.0, rows * C * es * n, "hbm"
+    if name == "stgcn_bn_bwd_apply":
+        _, dt, rows, C = key
+        return 0.0, rows * C * es * 3, "hbm"
+    return 0.0, 0.0, "hbm"
+
+
+def cpu_baseline(n_clips, steps, threads):
+    """The CPU oracle's training step (float32 torch CPU ops), bounded sample of the same workload."""
+    from oracle import stgcn_oracle as O
+    torch.set_num_threads(threads)
+    g = O.build_graph("ntu-rgb+d", "spatial")
+    sd = O.det_state(3, 60, g["A"], True, dtype=torch.float32)
+    gen = torch.Generator().manual_seed(0)
+    x = torch.randn(n_clips, 3, 300, 25, 2, generator=gen)
+    labels = torch.randint(0, 60, (n_clips,), generator=gen)
+    names = O.param_names(sd)
+    moms = {}
+    seeds = list(range(1, 11))
+    times = []
+    for it in range(steps + 1):
+        t0 = time.perf_counter()
+        logits, cache, newb = O.model_forward(sd, x, True, dropout=0.5, seeds=seeds)
+        loss, dlog = O.cross_entropy(logits, labels)
+        grads = O.model_backward(sd, cache, dlog, True)
+        prm = {k: sd[k] for k in names}
+        O.sgd_nesterov_step(prm, grads, moms, 0.1)
+        sd.update(prm)
+        sd.update(newb)
+        if it > 0:                                              # first iteration warms the allocator up
+            times.append(time.perf_counter() - t0)
+    t = sum(times) / len(times)
+    return {"value": round(n_clips / t, 3), "unit": "clips/s", "cores": threads, "kind": "port",
+            "sample": "%d timed oracle steps (1 warm-up) at N=%d clips, T=300, V=25, M=2, float32, dropout 0.5, SGD-nesterov" % (steps, n_clips)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--batch", type=int, default=64, help="clips per GPU")
+    ap.add_argument("--frames", type=int, default=300)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-clips", type=int, default=2)
+    ap.add_argument("--kernel-table", action="store_true", help="print the per-kernel time table to stderr")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the ST-GCN HIP path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+    if args.gpus != world and rank == 0:
+        print("note: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
+
+    from net.st_gcn import Model
+    from stgcn_rt import ops as P
+    from stgcn_rt.ddp import Trainer
+
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    torch.manual_seed(1234)
+    model = Model(3, 60, dict(layout="ntu-rgb+d", strategy="spatial"), True, dropout=0.5, compute_dtype=dtype).to(dev)
+
+    def weights_init(m):                                        # processor/recognition.py:21-33
+        cn = m.__class__.__name__
+        if cn.find("Conv1d") != -1 or cn.find("Conv2d") != -1:
+            m.weight.data.normal_(0.0, 0.02)
+            if m.bias is not None:
+                m.bias.data.fill_(0)
+        elif cn.find("BatchNorm") != -1:
+            m.weight.data.normal_(1.0, 0.02)
+            m.bias.data.fill_(0)
+    model.apply(weights_init)
+    model.train()
+    trainer = Trainer(model, lr=0.1, momentum=0.9, weight_decay=1e-4, nesterov=True)
+    trainer.broadcast_from_rank0()
+
+    gen = torch.Generator().manual_seed(rank)                   # synthetic data: x ~ N(0,1), labels uniform
+    x = torch.randn(args.batch, 3, args.frames, 25, 2, generator=gen).to(dev)
+    labels = torch.randint(0, 60, (args.batch,), generator=gen).to(dev)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # warm-up; the last warm-up step also records every kernel to find the one that dominates
+    for i in range(args.warmup):
+        if i == args.warmup - 1:
+            P.TIMING, P.TIMING_NAMES = {}, None
+        trainer.step(x, labels)
+    table = P.timing_summary() if P.TIMING is not None else {}
+    P.TIMING = None
+    by_name = {}
+    for k, (n, mean, tot) in table.items():
+        by_name[k[0]] = by_name.get(k[0], 0.0) + tot
+    dom_name = max(by_name, key=by_name.get) if by_name else None
+    if args.kernel_table and rank == 0:
+        tot_all = sum(by_name.values())
+        print("per-kernel time of one step (ms), total %.2f" % tot_all, file=sys.stderr)
+        for k, (n, mean, tot) in sorted(table.items(), key=lambda kv: -kv[1][2]):
+            fl, by, bound = kernel_work(k)
+            print("  %7.3f ms x%-2d  %6.1f TFLOP/s %7.1f GB/s  %s" % (mean, n, fl / mean / 1e9, by / mean / 1e6, k), file=sys.stderr)
+
+    # timed region: only the dominant kernel is bracketed by events
+    if dom_name is not None:
+        P.TIMING, P.TIMING_NAMES = {}, {dom_name}
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = trainer.step(x, labels)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    timed = P.timing_summary() if P.TIMING is not None else {}
+    P.TIMING = None
+
+    if rank == 0:
+        clips = args.batch * world * args.steps
+        roof = None
+        if timed:
+            # dominant instance = the key with the largest total time
+            key, (n, mean, tot) = max(timed.items(), key=lambda kv: kv[1][2])
+            fl, by, bound = kernel_work(key)
+            if bound == "mfma":
+                ach, peak, unit = fl / mean / 1e9, PEAK[args.dtype], "TFLOP/s"
+            else:
+                ach, peak, unit = by / mean / 1e6, HBM_PEAK, "GB/s"
+            roof = {"bound": bound, "achieved": round(ach, 2), "peak": peak, "unit": unit, "frac": round(ach / peak, 4),
+                    "traffic": None, "kernel": key[0].replace("stgcn_", ""), "launch": list(map(str, key[1:])),
+                    "avg_launch_ms": round(mean, 4), "launches_timed": n,
+                    "share_of_step": round(sum(v[2] for v in timed.values()) / (elapsed * 1e3), 3)}
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline(args.cpu_clips, 2, min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16"))))
+        line = {
+            "metric": "train clips/sec, ST-GCN NTU-60 (T=300,V=25,M=2)", "value": round(clips / elapsed, 2), "unit": "clips/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "NTU-RGB+D xsub training step (forward + cross-entropy + backward + SGD-nesterov), "
+                                   "%d clips per GPU, T=%d, V=25, M=2, 60 classes, spatial K=3, dropout 0.5" % (args.batch, args.frames),
+                       "global_batch": args.batch * world, "parallelism": "dp%d" % world, "final_loss": round(float(loss.item()), 4)},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

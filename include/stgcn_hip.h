@@ -1,0 +1,145 @@
+/* C ABI of libstgcn_hip.so: hand-written gfx950 (MI355X) kernels for the ST-GCN hot path.
+ *
+ * The reference (hensyou/st-gcn) has no FFI: its hot path is reached as a Python module
+ * (net.st_gcn.Model / net.utils.tgcn.ConvTemporalGraphical) whose arithmetic is delegated to
+ * stock PyTorch operators.  Each entry point below replaces the operator call(s) cited with it.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is DEVICE memory owned by the caller;
+ *   - activations are channels-last: physical [B][T][V][C], C contiguous (a torch tensor of
+ *     logical shape [B,C,T,V] in torch.channels_last memory format); dtype STGCN_F32 or
+ *     STGCN_BF16; per-channel parameters and all gradients of parameters are float32;
+ *   - `stream` is a hipStream_t; calls only enqueue work: no allocation, no synchronisation;
+ *   - return value: 0 ok, 1 invalid argument, 2 launch failed, 3 workspace too small;
+ *   - `stats` buffers are double[2*C]; kernels ADD into them, the caller zeroes them first;
+ *   - channel counts of MFMA operands must be multiples of one 32-byte k-step (16 bf16 / 8 f32);
+ *     conv_rows / conv_wgrad input channels multiples of one 128-byte chunk (64 bf16 / 32 f32).
+ */
+#ifndef STGCN_HIP_H
+#define STGCN_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define STGCN_F32 0
+#define STGCN_BF16 1
+#define STGCN_EPI_PLAIN 0    /* out = acc + bias;                   stats += [sum out, sum out^2]        */
+#define STGCN_EPI_RELU_BWD 1 /* out = (ep_scale*aux+ep_shift>0)?acc:0; stats += [sum out, sum out*xhat(aux)] */
+
+/* Convolution along T as an implicit GEMM (MFMA):
+ *   out[b,to,v,co] = bias[co] + sum_tap sum_ci pro(in[b, ti, v, ci]) * w[tap][co][ci]
+ *   forward form ti = stride*to - pad + tap*dil; transposed form ti = (to + pad - tap*dil)/stride when divisible;
+ *   pro(x) = relu(pro_scale*x + pro_shift) when given (BatchNorm + ReLU ahead of the conv).
+ * Replaces: nn.Conv2d(C,C,(9,1),(s,1),(4,0)) forward of st_gcn.tcn (net/st_gcn.py:162-168) fused with the
+ * preceding BatchNorm2d+ReLU (st_gcn.py:160-161) and the statistics pass of the following BatchNorm2d (st_gcn.py:169);
+ * the residual nn.Conv2d(Cin,Cout,1,(s,1)) (st_gcn.py:181-185); Model.extract_feature's per-position fcn
+ * (st_gcn.py:113); and, in the transposed form, their input gradients (autograd of the same lines), with
+ * STGCN_EPI_RELU_BWD fusing the ReLU mask and the reduction pass of the BatchNorm backward. */
+int stgcn_conv_rows(int dtype, const void* in, const void* w_packed, void* out,
+                    const float* bias, const float* pro_scale, const float* pro_shift,
+                    int epilogue, const void* aux, const float* ep_scale, const float* ep_shift,
+                    const float* ep_mean, const float* ep_rstd, double* stats,
+                    int B, int Tin, int Tout, int V, int Cin, int Cout,
+                    int ntaps, int stride, int pad, int dil, int transposed, void* stream);
+
+/* Weight gradient of the forward form above: dW[co][ci][tap] (float32, the torch conv weight layout).
+ * Replaces: autograd weight gradient of the convolutions at net/st_gcn.py:162-168 and 181-185.
+ * workspace: partial-sum slab, at least ntaps*Cout*Cin*4 bytes (more lets more workgroups run). */
+int stgcn_conv_wgrad(int dtype, const void* in, const void* dout, float* dW,
+                     const float* pro_scale, const float* pro_shift,
+                     int B, int Tin, int Tout, int V, int Cin, int Cout,
+                     int ntaps, int stride, int pad, int dil,
+                     void* workspace, size_t workspace_bytes, void* stream);
+
+/* Fused graph convolution over NF = B*T frames:
+ *   out[f,a,n] = sum_k sum_b adj[k][a][b] * (sum_c in[f,b,c]*w[k][n][c] + bias[k][n])  (+ add[f,a,n])
+ * Forward:  adj[k][w][v] = (A*importance)[k][v][w], w[k][co][ci] = conv.weight[k*Cout+co][ci].
+ * Backward: adj[k][v][w] = (A*importance)[k][v][w], w[k][ci][co] = conv.weight[k*Cout+co][ci], no bias.
+ * Replaces: ConvTemporalGraphical.forward -- nn.Conv2d 1x1 (net/utils/tgcn.py:60), view (tgcn.py:62-63) and
+ * torch.einsum('nkctv,kvw->nctw') (tgcn.py:64) -- and its input gradient; the K*C intermediate stays in registers. */
+int stgcn_gcn_fused(int dtype, const void* in, const void* w_packed, const float* adj, const float* bias,
+                    void* out, const void* add, double* stats,
+                    int NF, int V, int Cin, int Nout, int K, void* stream);
+
+/* dA[k][v][w] = sum_{f,co} (sum_ci w[k][co][ci] x[f,v,ci] + bias[k][co]) * dy[f,w,co]   (K <= 3 per call)
+ * Replaces: autograd gradient of the einsum w.r.t. A (tgcn.py:64), i.e. of A*importance (net/st_gcn.py:82). */
+int stgcn_gcn_agrad(int dtype, const void* x, const void* w_packed, const float* bias, const void* dy,
+                    float* dA, int NF, int V, int Cin, int Cout, int K,
+                    void* workspace, size_t workspace_bytes, void* stream);
+
+/* dW[k][co][ci] = sum_{f,v} (sum_w adj[k][v][w] dy[f,w,co]) x[f,v,ci];  db[k][co] = sum of the same bracket.
+ * adj = (A*importance)[k][v][w].  K <= 3 per call.
+ * Replaces: autograd gradients of conv.weight / conv.bias of ConvTemporalGraphical (tgcn.py:48-55, 60). */
+int stgcn_gcn_wgrad(int dtype, const void* x, const void* dy, const float* adj, float* dW, float* db,
+                    int NF, int V, int Cin, int Cout, int K,
+                    void* workspace, size_t workspace_bytes, void* stream);
+
+/* BatchNorm bookkeeping: batch statistics -> mean / rstd / scale=gamma*rstd / shift=beta-mean*scale, running
+ * statistics update (momentum, unbiased variance); eval mode reads the running statistics instead.
+ * Replaces: the statistics half of nn.BatchNorm2d / nn.BatchNorm1d (net/st_gcn.py:42,160,169,186). */
+int stgcn_bn_finalize(const double* stats, double count, const float* gamma, const float* beta,
+                      float* running_mean, float* running_var, float momentum, float eps,
+                      float* mean, float* rstd, float* scale, float* shift, int C, int training, void* stream);
+
+/* dbeta = stats[0..C), dgamma = stats[C..2C) as float32. */
+int stgcn_stats_to_grads(const double* stats, float* dgamma, float* dbeta, int C, void* stream);
+
+/* out = relu((scale2*o + shift2) * keep/(1-p) + res'), res' = res_scale*res + res_shift | res | 0.
+ * Replaces: BatchNorm2d apply + Dropout + residual add + ReLU (net/st_gcn.py:169-170, 193-197). */
+int stgcn_block_out_fwd(int dtype, const void* o, const void* res, void* out,
+                        const float* scale2, const float* shift2, const float* res_scale, const float* res_shift,
+                        size_t rows, int C, float drop_p, uint32_t seed, void* stream);
+
+/* Backward of the stage above.  pass 0: per-channel sums (stats2, statsr).  pass 1: dO (BatchNorm backward of the
+ * main branch), dR (same for a conv residual), g (= masked incoming gradient, for an identity residual), and the
+ * bias gradients of the two convolutions (dbias_*).  The incoming gradient is dout and/or dpool (float32 [B][C],
+ * constant over (t,v): the gradient of the global average pool).
+ * Replaces: autograd of net/st_gcn.py:169-170, 193-197 (and of F.avg_pool2d, st_gcn.py:85, for dpool). */
+int stgcn_block_out_bwd(int dtype, int pass, const void* dout, const float* dpool, size_t rows_per_sample,
+                        const void* out, const void* o, const void* r,
+                        const float* mean2, const float* rstd2, const float* gamma2,
+                        const float* meanr, const float* rstdr, const float* gammar,
+                        double* stats2, double* statsr, void* dO, void* dR, void* g,
+                        double* dbias_o, double* dbias_r,
+                        size_t rows, int C, float drop_p, uint32_t seed, double count, int training, void* stream);
+
+/* dy = gamma*rstd*(g - S1/n - yhat*S2/n)  (eval: g*gamma*rstd).  Replaces: autograd of BatchNorm2d (st_gcn.py:160). */
+int stgcn_bn_bwd_apply(int dtype, const void* g, const void* y, void* dy, const float* gamma,
+                       const float* mean, const float* rstd, const double* stats, double count,
+                       size_t rows, int C, int training, void* stream);
+
+/* data_bn: BatchNorm1d over channel v*C+c of x[N,C,T,V,M] (float32) and the two permutes around it.
+ * Replaces: net/st_gcn.py:72-78 (output is the channels-last [N*M][T][V][Cp] activation, Cp >= C zero padded). */
+int stgcn_data_bn_stats(const float* x, double* stats, int N, int C, int T, int V, int M, void* stream);
+int stgcn_data_bn_apply(int dtype, const float* x, void* out, const float* scale, const float* shift,
+                        int N, int C, int T, int V, int M, int Cp, void* stream);
+int stgcn_data_bn_bwd(int dtype, const void* dx0, const float* x, const float* mean, const float* rstd, double* stats,
+                      int N, int C, int T, int V, int M, int Cp, void* stream);
+
+/* Head.  Replaces: F.avg_pool2d over (T,V) (st_gcn.py:85), mean over M (st_gcn.py:86), fcn 1x1 conv (st_gcn.py:89-90). */
+int stgcn_pool_fwd(int dtype, const void* feat, float* pooled, int B, int R, int C, void* stream);
+int stgcn_pool_bwd(int dtype, const float* dpm, void* dfeat, int B, int R, int C, int M, void* stream);
+int stgcn_head_fc_fwd(const float* pooled, const float* W, const float* bias, float* logits,
+                      int N, int M, int C, int ncls, void* stream);
+int stgcn_head_fc_bwd(const float* dlogits, const float* pooled, const float* W, float* dW, float* db, float* dpm,
+                      int N, int M, int C, int ncls, void* stream);
+
+/* SGD with momentum / Nesterov / weight decay over flat float32 buffers; g is multiplied by grad_scale first.
+ * Replaces: optim.SGD(...).step() as configured at processor/recognition.py:46-53. */
+int stgcn_sgd_step(float* params, const float* grads, float* momentum_buf, size_t n,
+                   float lr, float momentum, float weight_decay, int nesterov, int first_step, float grad_scale,
+                   void* stream);
+
+/* Diagnostics. */
+int stgcn_probe_tr16(short* out, void* stream);
+int stgcn_version(void);
+const char* stgcn_arch(void);
+int stgcn_device_count(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -128,9 +128,9 @@ __global__ __launch_bounds__(256) void block_out_fwd_kernel(BlockOutArgs a) {
     }
 }
 
-static inline unsigned ew_grid(size_t rows, int rows_per_block) {
+static inline unsigned ew_grid(size_t rows, int rows_per_block, size_t cap = 2048) {
     size_t g = (rows + rows_per_block - 1) / rows_per_block;
-    if (g > 2048) g = 2048;
+    if (g > cap) g = cap;
     if (g < 1) g = 1;
     return (unsigned)g;
 }
@@ -316,12 +316,12 @@ extern "C" int stgcn_block_out_bwd(int dtype, int pass, const void* dout, const 
     hipStream_t st = (hipStream_t)stream;
     if (dtype == STGCN_BF16) {
         if (!ew_ok<bf16>(C)) return STGCN_ERR_ARG;
-        const unsigned gr = ew_grid(rows, ew_rpi<bf16>(C));
+        const unsigned gr = ew_grid(rows, ew_rpi<bf16>(C), 512);   // every workgroup ends in C*NS double atomics
         if (pass == 0) hipLaunchKernelGGL(block_out_bwd_reduce_kernel<bf16>, dim3(gr), dim3(256), 0, st, a);
         else hipLaunchKernelGGL(block_out_bwd_apply_kernel<bf16>, dim3(gr), dim3(256), 0, st, a);
     } else if (dtype == STGCN_F32) {
         if (!ew_ok<float>(C)) return STGCN_ERR_ARG;
-        const unsigned gr = ew_grid(rows, ew_rpi<float>(C));
+        const unsigned gr = ew_grid(rows, ew_rpi<float>(C), 512);
         if (pass == 0) hipLaunchKernelGGL(block_out_bwd_reduce_kernel<float>, dim3(gr), dim3(256), 0, st, a);
         else hipLaunchKernelGGL(block_out_bwd_apply_kernel<float>, dim3(gr), dim3(256), 0, st, a);
     } else return STGCN_ERR_ARG;

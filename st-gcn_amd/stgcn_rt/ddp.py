@@ -1,0 +1,176 @@
+"""Data-parallel training support: flat parameter / gradient buffers, bucketed gradient
+all-reduce overlapped with backward, and the fused SGD update.
+
+Replaces the reference's nn.DataParallel wrap (processor/io.py:86-87 of hensyou/st-gcn) with
+one process per GPU: every rank holds a full replica, runs the model on its own shard of the
+batch (BatchNorm statistics stay per replica, as under DataParallel), and gradients are
+averaged with a few large all-reduces over RCCL/xGMI.  Buckets follow reverse execution order
+(fcn, block 9 ... block 0, data_bn) and each is launched as soon as its last gradient has been
+accumulated, so communication overlaps the rest of backward.  The optimizer step is one HIP
+kernel over the flat buffers (torch.optim.SGD semantics: processor/recognition.py:46-53).
+"""
+import torch
+import torch.distributed as dist
+
+
+class FlatParams:
+    """Re-homes every parameter of `module` (and its .grad) as a view into one flat float32 buffer."""
+
+    def __init__(self, module, order=None):
+        params = [p for p in module.parameters() if p.requires_grad]
+        if order is not None:
+            params = order(params)
+        self.params = params
+        self.sizes = [p.numel() for p in params]
+        self.offsets = [0]
+        for n in self.sizes:
+            self.offsets.append(self.offsets[-1] + n)
+        total = self.offsets[-1]
+        dev = params[0].device
+        self.flat = torch.empty(total, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.mom = torch.zeros(total, dtype=torch.float32, device=dev)
+        with torch.no_grad():
+            for p, o, n in zip(params, self.offsets, self.sizes):
+                self.flat[o:o + n].copy_(p.detach().reshape(-1))
+                p.data = self.flat[o:o + n].view(p.shape)
+                p.grad = self.grad[o:o + n].view(p.shape)
+        self.steps = 0
+
+    def zero_grad(self):
+        self.grad.zero_()
+        for p, o, n in zip(self.params, self.offsets, self.sizes):
+            if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * o:
+                p.grad = self.grad[o:o + n].view(p.shape)
+
+
+def reverse_execution_order(model):
+    """Parameter order in which gradients become ready: fcn, block 9 ... block 0, data_bn."""
+    def order(params):
+        ids = {id(p) for p in params}
+        out = []
+        def take(mod):
+            for p in mod.parameters():
+                if id(p) in ids and all(p is not q for q in out):
+                    out.append(p)
+        take(model.fcn)
+        ei = getattr(model, "edge_importance", None)
+        for i in reversed(range(len(model.st_gcn_networks))):
+            take(model.st_gcn_networks[i])
+            if isinstance(ei, torch.nn.ParameterList):
+                if all(ei[i] is not q for q in out):
+                    out.append(ei[i])
+        take(model.data_bn)
+        for p in params:                      # anything not covered above
+            if all(p is not q for q in out):
+                out.append(p)
+        return out
+    return order
+
+
+class GradBucketer:
+    """Bucketed asynchronous all-reduce of a FlatParams gradient buffer.
+
+    Works with any process group (RCCL on GPUs, gloo on CPU).  Buckets are contiguous slices of the
+    flat gradient; a bucket is reduced when every parameter in it has received its gradient."""
+
+    def __init__(self, flat, bucket_bytes=4 << 20, group=None):
+        self.flat = flat
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.buckets = []                     # (start, end, [param indices])
+        start, idxs, nbytes = 0, [], 0
+        for i, n in enumerate(flat.sizes):
+            idxs.append(i)
+            nbytes += 4 * n
+            if nbytes >= bucket_bytes:
+                self.buckets.append((start, flat.offsets[i + 1], idxs))
+                start, idxs, nbytes = flat.offsets[i + 1], [], 0
+        if idxs:
+            self.buckets.append((start, flat.offsets[-1], idxs))
+        self.bucket_of = {}
+        for b, (_, _, idx) in enumerate(self.buckets):
+            for i in idx:
+                self.bucket_of[i] = b
+        self.pending = [0] * len(self.buckets)
+        self.handles = []
+        self.launched = []
+        if self.world > 1:
+            for i, p in enumerate(flat.params):
+                p.register_post_accumulate_grad_hook(self._make_hook(i))
+        self.reset()
+
+    def reset(self):
+        self.pending = [len(idx) for (_, _, idx) in self.buckets]
+        self.handles = []
+        self.launched = []
+
+    def _make_hook(self, i):
+        def hook(param):
+            b = self.bucket_of[i]
+            self.pending[b] -= 1
+            if self.pending[b] == 0:
+                self._launch(b)
+        return hook
+
+    def _launch(self, b):
+        s, e, _ = self.buckets[b]
+        self.launched.append(b)
+        self.handles.append(dist.all_reduce(self.flat.grad[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def finish(self):
+        """Launch whatever was not triggered by hooks (unused parameters), wait for all buckets.
+        Gradients hold the SUM over ranks afterwards; the optimizer divides by the world size."""
+        if self.world > 1:
+            for b in range(len(self.buckets)):
+                if b not in self.launched:
+                    self._launch(b)
+            for h in self.handles:
+                h.wait()
+        return 1.0 / self.world
+
+
+class SGD:
+    """torch.optim.SGD(momentum, nesterov, weight_decay) over the flat buffers, one HIP kernel per step."""
+
+    def __init__(self, flat, lr, momentum=0.9, weight_decay=1e-4, nesterov=True):
+        self.flat, self.lr, self.momentum, self.weight_decay, self.nesterov = flat, lr, momentum, weight_decay, nesterov
+
+    def step(self, grad_scale=1.0):
+        from . import ops as P
+        P.sgd_step(self.flat.flat, self.flat.grad, self.flat.mom, self.lr, self.momentum, self.weight_decay,
+                   self.nesterov, self.flat.steps == 0, grad_scale)
+        self.flat.steps += 1
+
+
+def adjust_lr(base_lr, epoch, steps):
+    """Step schedule of the reference (processor/recognition.py:62-70)."""
+    return base_lr * (0.1 ** sum(1 for s in steps if epoch >= s))
+
+
+class Trainer:
+    """One training iteration as REC_Processor.train does it (processor/recognition.py:84-97):
+    forward, mean cross-entropy, backward, (all-reduce), SGD-nesterov update."""
+
+    def __init__(self, model, lr=0.1, momentum=0.9, weight_decay=1e-4, nesterov=True, bucket_bytes=4 << 20):
+        self.model = model
+        self.flat = FlatParams(model, reverse_execution_order(model))
+        self.bucketer = GradBucketer(self.flat, bucket_bytes)
+        self.opt = SGD(self.flat, lr, momentum, weight_decay, nesterov)
+        self.loss_fn = torch.nn.CrossEntropyLoss()
+
+    def broadcast_from_rank0(self):
+        if self.bucketer.world > 1:
+            dist.broadcast(self.flat.flat, src=0)
+            for b in self.model.buffers():
+                dist.broadcast(b, src=0)
+
+    def step(self, data, label):
+        self.flat.zero_grad()
+        self.bucketer.reset()
+        out = self.model(data)
+        loss = self.loss_fn(out, label)
+        loss.backward()
+        scale = self.bucketer.finish()
+        self.opt.step(scale)
+        return loss

@@ -12,6 +12,32 @@ from . import lib as L
 CL = torch.channels_last
 _ws = {}
 
+# Per-kernel timing (bench / profiling aid): when TIMING is a dict, every launch of a kernel whose name is
+# in TIMING_NAMES (None = all) is bracketed by events on the current stream, keyed by kernel name + shape.
+TIMING = None
+TIMING_NAMES = None
+
+
+def _launch(key, name, *args):
+    if TIMING is None or (TIMING_NAMES is not None and name not in TIMING_NAMES):
+        return L.call(name, *args)
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    L.call(name, *args)
+    e1.record()
+    TIMING.setdefault((name,) + tuple(key), []).append((e0, e1))
+
+
+def timing_summary():
+    """{key: (launches, mean ms, total ms)} of the recorded events (synchronises)."""
+    torch.cuda.synchronize()
+    out = {}
+    for k, evs in (TIMING or {}).items():
+        ms = [a.elapsed_time(b) for a, b in evs]
+        out[k] = (len(ms), sum(ms) / len(ms), sum(ms))
+    return out
+
 
 def kstep(dtype):
     """Channel granularity of the MFMA kernels: one 32-byte k-step."""
@@ -98,7 +124,8 @@ def conv_rows(x, w_packed, Cout, Tout, bias=None, pro=None, epilogue=L.EPI_PLAIN
         out = new_act(B, Cout, Tout, V, x.dtype, x.device)
     ps, pb = pro if pro is not None else (None, None)
     es, eb, em, er = ep if ep is not None else (None, None, None, None)
-    L.call("stgcn_conv_rows", L.dtype_code(x.dtype), L.ptr(x), L.ptr(w_packed), L.ptr(out), L.ptr(bias), L.ptr(ps), L.ptr(pb),
+    _launch((str(x.dtype), "T" if transposed else "F", epilogue, B, Tin, Tout, V, Cin, Cout, ntaps, stride, pro is not None),
+            "stgcn_conv_rows", L.dtype_code(x.dtype), L.ptr(x), L.ptr(w_packed), L.ptr(out), L.ptr(bias), L.ptr(ps), L.ptr(pb),
            epilogue, L.ptr(aux), L.ptr(es), L.ptr(eb), L.ptr(em), L.ptr(er), L.ptr(stats),
            B, Tin, Tout, V, Cin, Cout, ntaps, stride, pad, dil, 1 if transposed else 0, L.stream_ptr())
     return out
@@ -111,7 +138,7 @@ def conv_wgrad(x, dout, ntaps, stride, pad, dil=1, pro=None):
     dW = torch.empty((Cout, Cin, ntaps, 1), dtype=torch.float32, device=x.device)
     ws = workspace(x.device)
     ps, pb = pro if pro is not None else (None, None)
-    L.call("stgcn_conv_wgrad", L.dtype_code(x.dtype), L.ptr(x), L.ptr(dout), L.ptr(dW), L.ptr(ps), L.ptr(pb),
+    _launch((str(x.dtype), B, Tin, Tout, V, Cin, Cout, ntaps, stride), "stgcn_conv_wgrad", L.dtype_code(x.dtype), L.ptr(x), L.ptr(dout), L.ptr(dW), L.ptr(ps), L.ptr(pb),
            B, Tin, Tout, V, Cin, Cout, ntaps, stride, pad, dil, L.ptr(ws), ws.numel(), L.stream_ptr())
     return dW
 
@@ -121,7 +148,7 @@ def gcn_fused(x, w_packed, adj, Nout, bias=None, add=None, stats=None):
     B, Cin, T, V = x.shape
     K = adj.shape[0]
     out = new_act(B, Nout, T, V, x.dtype, x.device)
-    L.call("stgcn_gcn_fused", L.dtype_code(x.dtype), L.ptr(x), L.ptr(w_packed), L.ptr(adj), L.ptr(bias), L.ptr(out), L.ptr(add),
+    _launch((str(x.dtype), B * T, V, Cin, Nout, K, add is not None), "stgcn_gcn_fused", L.dtype_code(x.dtype), L.ptr(x), L.ptr(w_packed), L.ptr(adj), L.ptr(bias), L.ptr(out), L.ptr(add),
            L.ptr(stats), B * T, V, Cin, Nout, K, L.stream_ptr())
     return out
 
@@ -138,7 +165,7 @@ def gcn_agrad(x, w_packed, bias, dy):
     ws = workspace(x.device)
     for k0, kn in _kgroups(K):
         bk = None if bias is None else bias[k0 * Cout:(k0 + kn) * Cout]
-        L.call("stgcn_gcn_agrad", L.dtype_code(x.dtype), L.ptr(x), L.ptr(w_packed[k0:k0 + kn]), L.ptr(bk), L.ptr(dy), L.ptr(dA[k0:k0 + kn]),
+        _launch((str(x.dtype), B * T, V, Cin, Cout, kn), "stgcn_gcn_agrad", L.dtype_code(x.dtype), L.ptr(x), L.ptr(w_packed[k0:k0 + kn]), L.ptr(bk), L.ptr(dy), L.ptr(dA[k0:k0 + kn]),
                B * T, V, Cin, Cout, kn, L.ptr(ws), ws.numel(), L.stream_ptr())
     return dA
 
@@ -153,7 +180,7 @@ def gcn_wgrad(x, dy, adj, need_bias=True):
     ws = workspace(x.device)
     for k0, kn in _kgroups(K):
         dbk = None if db is None else db[k0 * Cout:(k0 + kn) * Cout]
-        L.call("stgcn_gcn_wgrad", L.dtype_code(x.dtype), L.ptr(x), L.ptr(dy), L.ptr(adj[k0:k0 + kn]), L.ptr(dW[k0:k0 + kn]), L.ptr(dbk),
+        _launch((str(x.dtype), B * T, V, Cin, Cout, kn), "stgcn_gcn_wgrad", L.dtype_code(x.dtype), L.ptr(x), L.ptr(dy), L.ptr(adj[k0:k0 + kn]), L.ptr(dW[k0:k0 + kn]), L.ptr(dbk),
                B * T, V, Cin, Cout, kn, L.ptr(ws), ws.numel(), L.stream_ptr())
     return dW, db
 
@@ -186,7 +213,7 @@ def stats_to_grads(stats, Cc):
 def block_out_fwd(o, res, bn2, bnr, drop_p, seed):
     B, Cc, T, V = o.shape
     out = new_act(B, Cc, T, V, o.dtype, o.device)
-    L.call("stgcn_block_out_fwd", L.dtype_code(o.dtype), L.ptr(o), L.ptr(res), L.ptr(out), L.ptr(bn2.scale), L.ptr(bn2.shift),
+    _launch((str(o.dtype), B * T * V, Cc, res is not None, bnr is not None), "stgcn_block_out_fwd", L.dtype_code(o.dtype), L.ptr(o), L.ptr(res), L.ptr(out), L.ptr(bn2.scale), L.ptr(bn2.shift),
            L.ptr(bnr.scale) if bnr is not None else None, L.ptr(bnr.shift) if bnr is not None else None,
            B * T * V, Cc, float(drop_p), int(seed) & 0xFFFFFFFF, L.stream_ptr())
     return out
@@ -204,13 +231,13 @@ def block_out_bwd(dout, out, o, r, bn2, gamma2, bnr, gammar, want_g, drop_p, see
             L.ptr(bnr.mean) if has_r else None, L.ptr(bnr.rstd) if has_r else None, L.ptr(gammar) if has_r else None,
             L.ptr(stats2), L.ptr(statsr) if has_r else None, None, None, None, L.ptr(dbo), L.ptr(dbr) if has_r else None,
             rows, Cc, float(drop_p), int(seed) & 0xFFFFFFFF, float(rows), 1 if training else 0, L.stream_ptr()]
-    L.call("stgcn_block_out_bwd", *args)
+    _launch((str(o.dtype), 0, rows, Cc, has_r), "stgcn_block_out_bwd", *args)
     dO = new_act(B, Cc, T, V, o.dtype, o.device)
     dR = new_act(B, Cc, T, V, o.dtype, o.device) if has_r else None
     g = new_act(B, Cc, T, V, o.dtype, o.device) if want_g else None
     args[1] = 1
     args[16], args[17], args[18] = L.ptr(dO), L.ptr(dR), L.ptr(g)
-    L.call("stgcn_block_out_bwd", *args)
+    _launch((str(o.dtype), 1, rows, Cc, has_r, want_g), "stgcn_block_out_bwd", *args)
     return dO, dR, g, stats2, (statsr if has_r else None), dbo, (dbr if has_r else None)
 
 
@@ -218,7 +245,7 @@ def bn_bwd_apply(g, y, gamma, bn, stats, training, out=None):
     B, Cc, T, V = y.shape
     if out is None:
         out = new_act(B, Cc, T, V, y.dtype, y.device)
-    L.call("stgcn_bn_bwd_apply", L.dtype_code(y.dtype), L.ptr(g), L.ptr(y), L.ptr(out), L.ptr(gamma), L.ptr(bn.mean), L.ptr(bn.rstd),
+    _launch((str(y.dtype), B * T * V, Cc), "stgcn_bn_bwd_apply", L.dtype_code(y.dtype), L.ptr(g), L.ptr(y), L.ptr(out), L.ptr(gamma), L.ptr(bn.mean), L.ptr(bn.rstd),
            L.ptr(stats), float(B * T * V), B * T * V, Cc, 1 if training else 0, L.stream_ptr())
     return out
 

@@ -269,6 +269,11 @@ static int conv_rows_dispatch(ConvRowsArgs& a, int epi, hipStream_t stream) {
     return launch_conv_rows<T, 1, 2, EPI_PLAIN>(a, stream);
 }
 
+// fast path for the stride-1 temporal convolutions in bf16 (conv_t9.hip); -1 = shape not covered
+int conv_t9_try(const void* in, const void* w, void* out, const float* bias, const float* pro_scale, const float* pro_shift,
+                int epilogue, const void* aux, const float* ep_scale, const float* ep_shift, const float* ep_mean, const float* ep_rstd,
+                double* stats, int B, int T, int V, int Cin, int Cout, int ntaps, int transposed, hipStream_t stream);
+
 // C-ABI ------------------------------------------------------------------------------------
 extern "C" int stgcn_conv_rows(int dtype, const void* in, const void* w_packed, void* out,
                                const float* bias, const float* pro_scale, const float* pro_shift,
@@ -284,6 +289,12 @@ extern "C" int stgcn_conv_rows(int dtype, const void* in, const void* w_packed, 
     a.win_rows_max = 0; a.tiles_per_sample = 0;
     if (!in || !w_packed || !out) return STGCN_ERR_ARG;
     if ((pro_scale == nullptr) != (pro_shift == nullptr)) return STGCN_ERR_ARG;
+    if (dtype == STGCN_BF16 && stride == 1 && dil == 1 && ntaps >= 1 && pad == (ntaps - 1) / 2 && Tin == Tout && B > 0 && Tin > 0 &&
+        (epilogue == EPI_PLAIN || (aux && ep_scale && ep_shift && ep_mean && ep_rstd))) {
+        const int rc = conv_t9_try(in, w_packed, out, bias, pro_scale, pro_shift, epilogue, aux, ep_scale, ep_shift, ep_mean, ep_rstd,
+                                   stats, B, Tin, V, Cin, Cout, ntaps, transposed, (hipStream_t)stream);
+        if (rc >= 0) return rc;
+    }
     if (dtype == STGCN_BF16) return conv_rows_dispatch<bf16>(a, epilogue, (hipStream_t)stream);
     if (dtype == STGCN_F32) return conv_rows_dispatch<float>(a, epilogue, (hipStream_t)stream);
     return STGCN_ERR_ARG;

@@ -220,8 +220,9 @@ static int conv_wgrad_run(ConvWgradArgs& a, float* dW, size_t ws_bytes, hipStrea
     rc = hipGetLastError() == hipSuccess ? STGCN_OK : STGCN_ERR_LAUNCH;
     if (rc) return rc;
     const size_t n = (size_t)a.ntaps * a.Cout * a.Cin;
+    const int left = fold_parts(a.slab, nseg * wave_parts, n, stream);
     hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
-                       a.slab, dW, nseg * wave_parts, a.ntaps, a.Cout, a.Cin);
+                       a.slab, dW, left, a.ntaps, a.Cout, a.Cin);
     return hipGetLastError() == hipSuccess ? STGCN_OK : STGCN_ERR_LAUNCH;
 }
 

@@ -26,17 +26,14 @@ __device__ __forceinline__ void block_channel_reduce(float (*sums)[ET<T>::VEC], 
 #pragma unroll
         for (int j = 0; j < VEC; ++j) red[(threadIdx.x * NS + s) * VEC + j] = m.active ? sums[s][j] : 0.f;
     __syncthreads();
-    if (m.active && m.rl == 0) {
-#pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            if (!dst[s]) continue;
-#pragma unroll
-            for (int j = 0; j < VEC; ++j) {
-                float t = 0.f;
-                for (int r = 0; r < m.rpi; ++r) t += red[((r * m.cvs + m.cv) * NS + s) * VEC + j];
-                atomicAdd(&dst[s][m.cv * VEC + j], (double)t);
-            }
-        }
+    // one atomic per (sum, channel) per workgroup; consecutive threads hit consecutive addresses
+    for (int t = threadIdx.x; t < NS * C; t += 256) {
+        const int s = t / C, c = t - s * C;
+        if (!dst[s]) continue;
+        const int cv = c / VEC, j = c - cv * VEC;
+        float tot = 0.f;
+        for (int r = 0; r < m.rpi; ++r) tot += red[((r * m.cvs + cv) * NS + s) * VEC + j];
+        atomicAdd(&dst[s][c], (double)tot);
     }
 }
 
@@ -316,12 +313,12 @@ extern "C" int stgcn_block_out_bwd(int dtype, int pass, const void* dout, const 
     hipStream_t st = (hipStream_t)stream;
     if (dtype == STGCN_BF16) {
         if (!ew_ok<bf16>(C)) return STGCN_ERR_ARG;
-        const unsigned gr = ew_grid(rows, ew_rpi<bf16>(C), 512);   // every workgroup ends in C*NS double atomics
+        const unsigned gr = ew_grid(rows, ew_rpi<bf16>(C), 1024);   // every workgroup ends in C*NS double atomics
         if (pass == 0) hipLaunchKernelGGL(block_out_bwd_reduce_kernel<bf16>, dim3(gr), dim3(256), 0, st, a);
         else hipLaunchKernelGGL(block_out_bwd_apply_kernel<bf16>, dim3(gr), dim3(256), 0, st, a);
     } else if (dtype == STGCN_F32) {
         if (!ew_ok<float>(C)) return STGCN_ERR_ARG;
-        const unsigned gr = ew_grid(rows, ew_rpi<float>(C), 512);
+        const unsigned gr = ew_grid(rows, ew_rpi<float>(C), 1024);
         if (pass == 0) hipLaunchKernelGGL(block_out_bwd_reduce_kernel<float>, dim3(gr), dim3(256), 0, st, a);
         else hipLaunchKernelGGL(block_out_bwd_apply_kernel<float>, dim3(gr), dim3(256), 0, st, a);
     } else return STGCN_ERR_ARG;

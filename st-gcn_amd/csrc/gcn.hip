@@ -107,9 +107,17 @@ __global__ __launch_bounds__(256) void gcn_fused_kernel(GcnFusedArgs a) {
 
     const int NA = Cin / KSTEP;                  // 32-byte k-steps per row
     const int npass = (NA + 15) / 16;
-    float st1[4], st2[4];
+    constexpr int VEC = ET<T>::VEC;
+    // per-wave output staging: [32 joints][NTW*32 channels] in the storage dtype (+16 B pad per row)
+    const int SRS = NTW * 32 * ES + 16;
+    char* stage = tab + (size_t)K * tab_k_bytes + (size_t)wave * 32 * SRS;
+    const int ppr = NTW * 32 / VEC;              // 16-byte pieces per staged row (power of two)
+    const int pshift = 31 - __builtin_clz(ppr);
+    const int eseg = lane & (ppr - 1);           // this lane's fixed channel group in the store phase
+    const int ncols = min(NTW * 32, Nout - nbase);
+    float st1[VEC], st2[VEC];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { st1[i] = 0.f; st2[i] = 0.f; }
+    for (int i = 0; i < VEC; ++i) { st1[i] = 0.f; st2[i] = 0.f; }
 
     for (int f = blockIdx.x * 4 + wave; f < a.NF; f += gridDim.x * 4) {
         const int brow = min(l31, V - 1);        // rows >= V duplicate the last joint; adj zeroes them
@@ -146,35 +154,72 @@ __global__ __launch_bounds__(256) void gcn_fused_kernel(GcnFusedArgs a) {
                     }
                     chain_mma<T>(accy, accz, tab + (size_t)k * tab_k_bytes, lane);
                 }
-                // epilogue: lane = column n, register r = joint acc_row(r, h)
-                if (n < Nout) {
+                // lane = column n, register r = joint acc_row(r, h): park the tile in the wave's staging rows
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int aj = acc_row(r, h);
-                        if (aj < V) {
-                            const size_t o = ((size_t)f * V + aj) * Nout + n;
-                            float val = accy[r];
-                            if (a.add) val += load_elem<T>((const T*)a.add, o);
-                            st1[nt] += val;
-                            st2[nt] += val * val;
-                            store_elem<T>((T*)a.out, o, val);
-                        }
-                    }
+                for (int r = 0; r < 16; ++r) {
+                    const int aj = acc_row(r, h);
+                    if constexpr (ET<T>::IS_BF16)
+                        *(uint16_t*)(stage + aj * SRS + (nt * 32 + l31) * 2) = (uint16_t)(pack_bf16x2(accy[r], 0.f) & 0xFFFFu);
+                    else
+                        *(float*)(stage + aj * SRS + (nt * 32 + l31) * 4) = accy[r];
                 }
             }
         }
+        __builtin_amdgcn_wave_barrier();
+        // store phase: 16-byte pieces, whole channel rows coalesced; optional addend and statistics
+        const int npieces = V << pshift;
+        for (int p = lane; p < npieces; p += 64) {
+            const int row = p >> pshift;
+            const int col = eseg * VEC;
+            if (col < ncols) {
+                i32x4 v = *(const i32x4*)(stage + row * SRS + eseg * 16);
+                const size_t o = ((size_t)f * V + row) * Nout + nbase + col;
+                if (a.add || a.stats) {
+                    float fv[VEC];
+                    unpack16<T>(v, fv);
+                    if (a.add) {
+                        float av[VEC];
+                        unpack16<T>(*(const i32x4*)((const T*)a.add + o), av);
+#pragma unroll
+                        for (int j = 0; j < VEC; ++j) fv[j] += av[j];
+                        v = pack16<T>(fv);
+                        if constexpr (ET<T>::IS_BF16) unpack16<T>(v, fv);      // statistics of the stored values
+                    }
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) { st1[j] += fv[j]; st2[j] += fv[j] * fv[j]; }
+                }
+                *(i32x4*)((T*)a.out + o) = v;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
     }
     if (a.stats) {
+        // lanes with equal eseg hold partial sums of the same channels: fold them with shuffles, then the four
+        // waves through LDS, so that each workgroup issues ONE atomic per channel with consecutive lanes on
+        // consecutive addresses (scattered / repeated double atomics serialise at the memory side)
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-            if (nt < NTW) {
-                const int n = nbase + nt * 32 + l31;
-                const float s1 = st1[nt] + __shfl_xor(st1[nt], 32);
-                const float s2 = st2[nt] + __shfl_xor(st2[nt], 32);
-                if (h == 0 && n < Nout) {
-                    atomicAdd(&a.stats[n], (double)s1);
-                    atomicAdd(&a.stats[Nout + n], (double)s2);
-                }
+        for (int j = 0; j < VEC; ++j) {
+            for (int d = 32; d >= ppr; d >>= 1) {
+                st1[j] += __shfl_xor(st1[j], d);
+                st2[j] += __shfl_xor(st2[j], d);
+            }
+        }
+        __syncthreads();                               // every wave is done with its staging rows
+        float* red = (float*)(tab + (size_t)K * tab_k_bytes);      // [4 waves][2][NTW*32]
+        const int NC = NTW * 32;
+        if (lane < ppr) {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                red[(wave * 2 + 0) * NC + eseg * VEC + j] = st1[j];
+                red[(wave * 2 + 1) * NC + eseg * VEC + j] = st2[j];
+            }
+        }
+        __syncthreads();
+        for (int t = tid; t < 2 * NC; t += 256) {
+            const int which = t / NC, c = t - which * NC;
+            if (c < ncols) {
+                const float v = red[(0 * 2 + which) * NC + c] + red[(1 * 2 + which) * NC + c] + red[(2 * 2 + which) * NC + c] + red[(3 * 2 + which) * NC + c];
+                atomicAdd(&a.stats[which * Nout + nbase + c], (double)v);
             }
         }
     }
@@ -183,11 +228,12 @@ __global__ __launch_bounds__(256) void gcn_fused_kernel(GcnFusedArgs a) {
 template <typename T>
 static int gcn_fused_run(GcnFusedArgs& a, hipStream_t stream) {
     constexpr int ES = ET<T>::ES, KSTEP = ET<T>::KSTEP;
-    if (a.Cin % KSTEP != 0 || a.Cin <= 0 || a.Cin > 32 * KSTEP || a.Nout <= 0 || a.K < 1 || a.K > 8 || a.V < 1 || a.V > 32 || a.NF < 1) return STGCN_ERR_ARG;
+    if (a.Cin % KSTEP != 0 || a.Cin <= 0 || a.Cin > 32 * KSTEP || a.Nout <= 0 || a.Nout % ET<T>::VEC != 0 || a.K < 1 || a.K > 8 || a.V < 1 || a.V > 32 || a.NF < 1) return STGCN_ERR_ARG;
     const size_t rsw = (size_t)a.Cin * ES + 16;
     int ntw = 4;
     while (ntw > 1 && ((size_t)a.K * ntw * 32 * rsw + adj_chain_table_bytes<T>(a.K) > 72 * 1024 || (ntw - 1) * 32 >= a.Nout)) --ntw;
-    const size_t lds = (size_t)a.K * ntw * 32 * rsw + adj_chain_table_bytes<T>(a.K);
+    if (ntw == 3) ntw = 2;                       // the store phase wants a power-of-two piece count per row
+    const size_t lds = (size_t)a.K * ntw * 32 * rsw + adj_chain_table_bytes<T>(a.K) + (size_t)4 * 32 * (ntw * 32 * ES + 16);
     if (lds > 160 * 1024) return STGCN_ERR_ARG;
     a.ntw = ntw;
     const int gy = ceil_div_i(a.Nout, ntw * 32);
@@ -374,7 +420,8 @@ static int gcn_agrad_run(GcnAgradArgs& a, float* dA, size_t ws_bytes, hipStream_
     if (!set) { if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return STGCN_ERR_LAUNCH; set = true; }
     hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)gy), dim3(256), lds, stream, a);
     if (hipGetLastError() != hipSuccess) return STGCN_ERR_LAUNCH;
-    hipLaunchKernelGGL(sum_parts_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a.slab, dA, gx * gy * 4, n);
+    const int left = fold_parts(a.slab, gx * gy * 4, n, stream);
+    hipLaunchKernelGGL(sum_parts_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a.slab, dA, left, n);
     return hipGetLastError() == hipSuccess ? STGCN_OK : STGCN_ERR_LAUNCH;
 }
 
@@ -587,8 +634,12 @@ static int gcn_wgrad_run(GcnWgradArgs& a, float* dW, float* db, size_t ws_bytes,
     if (!set) { if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return STGCN_ERR_LAUNCH; set = true; }
     hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)ncot, (unsigned)ncig), dim3(256), lds, stream, a);
     if (hipGetLastError() != hipSuccess) return STGCN_ERR_LAUNCH;
-    hipLaunchKernelGGL(sum_parts_kernel, dim3((unsigned)((nW + 255) / 256)), dim3(256), 0, stream, a.slabW, dW, gx, nW);
-    if (db) hipLaunchKernelGGL(sum_parts_kernel, dim3((unsigned)((nB + 255) / 256)), dim3(256), 0, stream, a.slabB, db, gx, nB);
+    const int leftW = fold_parts(a.slabW, gx, nW, stream);
+    hipLaunchKernelGGL(sum_parts_kernel, dim3((unsigned)((nW + 255) / 256)), dim3(256), 0, stream, a.slabW, dW, leftW, nW);
+    if (db) {
+        const int leftB = fold_parts(a.slabB, gx, nB, stream);
+        hipLaunchKernelGGL(sum_parts_kernel, dim3((unsigned)((nB + 255) / 256)), dim3(256), 0, stream, a.slabB, db, leftB, nB);
+    }
     return hipGetLastError() == hipSuccess ? STGCN_OK : STGCN_ERR_LAUNCH;
 }
 

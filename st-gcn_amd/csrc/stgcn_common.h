@@ -116,3 +116,23 @@ __device__ __forceinline__ bool drop_keep(uint64_t idx, uint32_t seed, uint32_t 
 __device__ __forceinline__ i32x4 zero16() { i32x4 z = {0, 0, 0, 0}; return z; }
 
 static inline int ceil_div_i(int a, int b) { return (a + b - 1) / b; }
+
+// Two-stage fixed-order reduction of a partial-sum slab [nparts][n] (f32):
+//   stage 1 (fold_parts_kernel, grid (ceil(n/256), S)): part `s` <- sum of parts s, s+S, s+2S, ...   (in place)
+//   stage 2: the caller's final kernel sums the first S parts.
+// Every element is summed in the same order every run, so results are bitwise reproducible.
+__global__ static void fold_parts_kernel(float* slab, int nparts, size_t n, int S) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int s = blockIdx.y;
+    if (i >= n) return;
+    float acc = 0.f;
+    for (int p = s; p < nparts; p += S) acc += slab[(size_t)p * n + i];
+    slab[(size_t)s * n + i] = acc;
+}
+// returns the number of parts left to sum (<= 32)
+static inline int fold_parts(float* slab, int nparts, size_t n, hipStream_t stream) {
+    if (nparts <= 32) return nparts;
+    const int S = 32;
+    hipLaunchKernelGGL(fold_parts_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)S), dim3(256), 0, stream, slab, nparts, n, S);
+    return S;
+}

@@ -34,8 +34,17 @@ class GraphConvFn(torch.autograd.Function):
         Cout = W.shape[0] // K
         x = P.cl(x)
         A32 = A.detach().to(torch.float32)
-        wp = P.pack_gcn_w(W.detach(), K, cin_p, dtype)
-        y = P.gcn_fused(x, wp, A32.transpose(1, 2).contiguous(), Cout, bias=None if b is None else b.detach().float().contiguous())
+        cout_p = P.pad_to(Cout, P.kstep(dtype))          # kernels store whole 16-byte channel vectors
+        Wd = W.detach()
+        bias = None if b is None else b.detach().float()
+        if cout_p != Cout:
+            Wd = torch.nn.functional.pad(Wd.reshape(K, Cout, -1), (0, 0, 0, cout_p - Cout)).reshape(K * cout_p, -1, 1, 1)
+            if bias is not None:
+                bias = torch.nn.functional.pad(bias.reshape(K, Cout), (0, cout_p - Cout)).reshape(-1)
+        wp = P.pack_gcn_w(Wd, K, cin_p, dtype)
+        y = P.gcn_fused(x, wp, A32.transpose(1, 2).contiguous(), cout_p, bias=None if bias is None else bias.contiguous())
+        if cout_p != Cout:
+            y = P.cl(y[:, :Cout])
         ctx.save_for_backward(x, A32, W, b if b is not None else torch.empty(0))
         ctx.has_bias = b is not None
         ctx.cin_true = cin_true

@@ -185,6 +185,247 @@ __global__ void conv_wgrad_reduce_kernel(const float* slab, float* dW, int npart
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// bf16 fast path for "same"-padded temporal kernels with stride 1 or 2: persistent workgroups with an LDS ring,
+// as in conv_t9.  A workgroup owns one (64 co x 64 ci) tile pair for all taps (each wave a 32x32 quadrant,
+// 9 accumulators) and walks runs of consecutive output-row tiles of one sample.  Input rows (64-channel slice,
+// prologue applied, zeros outside the sample) sit in a 512-slot ring (slot = row & 511) so each is fetched once
+// per run; dout tiles are double-buffered.  The next tile's rows are fetched into registers under the MFMA phase.
+//   stride 1: 256 output rows per tile (16 k-steps), input advances 256 rows per tile.
+//   stride 2: OT whole output frames per tile (OT*V <= 128 rows, 8 k-steps), input advances 2*OT*V <= 256 rows;
+//             output row j of the tile pairs with input row  first + j + (j / V) * V + tap * V.
+struct ConvWgradRingArgs {
+    const void* in; const void* dout; float* slab;
+    const float* pro_scale; const float* pro_shift;
+    int B, Rin, Rout, V, Cin, Cout, ntaps;
+    int nruns, segs_per_sample, tiles_per_seg, tiles_per_sample;
+    int tile_rows;       // output rows one tile advances by (256, or OT*V for stride 2)
+};
+
+template <int STRIDE>
+__global__ __launch_bounds__(256) void conv_wgrad_ring_kernel(ConvWgradRingArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int RS = 144;
+    constexpr int KS = STRIDE == 1 ? 16 : 8;              // k-steps (16 output rows each) per tile
+    constexpr int DROWS = KS * 16;                        // dout rows per tile buffer
+    constexpr int DPASS = DROWS / 32;                     // staging passes for a dout tile
+    char* ring = smem;                                   // [512][RS]
+    char* dt = smem + 512 * RS;                          // 2 x [DROWS][RS]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int V = a.V, Rin = a.Rin, Rout = a.Rout, Cin = a.Cin, Cout = a.Cout, ntaps = a.ntaps;
+    const int half = (ntaps - 1) / 2;
+    const int co0 = blockIdx.y * 64, ci0 = blockIdx.z * 64;
+    const int coh = wave & 1, cih = wave >> 1;
+    const int q4 = (lane & 15) >> 2, p4 = lane & 3, g1 = (lane >> 4) & 1;
+    const int acol = (coh * 32 + 16 * g1 + 4 * p4) * 2;
+    const int bcol = (cih * 32 + 16 * g1 + 4 * p4) * 2;
+    const int tile_rows = a.tile_rows;
+    const int in_adv = STRIDE * tile_rows;                // input rows one tile advances by
+    const int span = STRIDE == 1 ? 256 + 2 * half * V : in_adv + (2 * half - 1) * V;   // input rows one tile touches
+
+    // stride 2: input-row offset of this lane's two address rows in every k-step (rows past the tile pair with
+    // zero dout rows; they are pointed at row 0 of the span, which always holds finite data)
+    int roff[STRIDE == 1 ? 1 : KS][2];
+    if constexpr (STRIDE != 1) {
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int j = 16 * s + 8 * h + q4 + 4 * u;
+                roff[s][u] = j < tile_rows ? j + (j / V) * V : 0;
+            }
+    }
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    const int sseg = tid & 7, srow = tid >> 3;           // staging: 32 rows per pass
+    float psc[8], psh[8];
+    const bool has_pro = a.pro_scale != nullptr;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        psc[j] = has_pro ? a.pro_scale[ci0 + sseg * 8 + j] : 1.f;
+        psh[j] = has_pro ? a.pro_shift[ci0 + sseg * 8 + j] : 0.f;
+    }
+    auto transform = [&](i32x4 v) -> i32x4 {
+        if (!has_pro) return v;
+        float f[8];
+        unpack16<bf16>(v, f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = fmaxf(fmaf(f[j], psc[j], psh[j]), 0.f);
+        return pack16<bf16>(f);
+    };
+    const bool co_ok = co0 + sseg * 8 < Cout;
+
+    for (int run = blockIdx.x; run < a.nruns; run += gridDim.x) {
+        const int b = run / a.segs_per_sample;
+        const int seg = run - b * a.segs_per_sample;
+        const int tile_beg = seg * a.tiles_per_seg;
+        const int tile_end = min(a.tiles_per_sample, tile_beg + a.tiles_per_seg);
+        if (tile_beg >= tile_end) continue;
+        const uint16_t* inb = (const uint16_t*)a.in + (size_t)b * Rin * Cin + ci0;
+        const uint16_t* dob = (const uint16_t*)a.dout + (size_t)b * Rout * Cout + co0;
+        i32x4 pf[8];
+        auto fetch_in = [&](int p_first) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int p = p_first + srow + 32 * i;
+                pf[i] = zero16();
+                if (p >= 0 && p < Rin) pf[i] = *(const i32x4*)(inb + (size_t)p * Cin + sseg * 8);
+            }
+        };
+        auto commit_in = [&](int p_first, int nrows) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int rel = srow + 32 * i;
+                const int p = p_first + rel;
+                if (rel < nrows) {
+                    i32x4 v = pf[i];
+                    if (p >= 0 && p < Rin) v = transform(v);
+                    *(i32x4*)(ring + (size_t)(p & 511) * RS + sseg * 16) = v;
+                }
+            }
+        };
+        auto fetch_do = [&](int p_first) {
+#pragma unroll
+            for (int i = 0; i < DPASS; ++i) {
+                const int rel = srow + 32 * i;
+                const int p = p_first + rel;
+                pf[i] = zero16();
+                if (rel < tile_rows && p < Rout && co_ok) pf[i] = *(const i32x4*)(dob + (size_t)p * Cout + sseg * 8);
+            }
+        };
+        auto commit_do = [&](int buf) {
+#pragma unroll
+            for (int i = 0; i < DPASS; ++i)
+                *(i32x4*)(dt + (size_t)buf * DROWS * RS + (srow + 32 * i) * RS + sseg * 16) = pf[i];
+        };
+
+        int p0 = tile_beg * tile_rows;                    // first output row of the tile
+        __syncthreads();                                  // previous run fully consumed
+        {
+            const int first = STRIDE * p0 - half * V;
+            for (int base = 0; base < span; base += 256) {
+                fetch_in(first + base);
+                commit_in(first + base, span - base);
+            }
+            fetch_do(p0);
+            commit_do(0);
+        }
+        int cur = 0;
+        for (int tile = tile_beg; tile < tile_end; ++tile, p0 += tile_rows) {
+            const bool more = tile + 1 < tile_end;
+            const int first = STRIDE * p0 - half * V;     // first input row of this tile's span
+            const int pnew = first + span;                // first input row the next tile adds
+            __syncthreads();                              // ring and dt[cur] visible
+            if (more) fetch_do(p0 + tile_rows);
+            const char* dcur = dt + (size_t)cur * DROWS * RS;
+            auto kstep = [&](int s, int ro0, int ro1) {
+                const int rowa = 16 * s + 8 * h + q4;
+                const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(dcur + rowa * RS + acol));
+                const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(dcur + (rowa + 4) * RS + acol));
+                const s16x8 af = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    if (t < ntaps) {
+                        const int r0 = (first + ro0 + t * V) & 511, r1 = (first + ro1 + t * V) & 511;
+                        const s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(ring + r0 * RS + bcol));
+                        const s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(ring + r1 * RS + bcol));
+                        const s16x8 bfv = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfv, acc[t], 0, 0, 0);
+                    }
+                }
+            };
+            if constexpr (STRIDE == 1) {
+#pragma unroll 1
+                for (int hs = 0; hs < 2; ++hs) {
+#pragma unroll 2
+                    for (int s8 = 0; s8 < 8; ++s8) {
+                        const int s = hs * 8 + s8;
+                        const int j = 16 * s + 8 * h + q4;
+                        kstep(s, j, j + 4);
+                    }
+                    if (hs == 0 && more) {
+                        commit_do(cur ^ 1);               // last read a tile ago: every wave has passed a barrier since
+                        fetch_in(pnew);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int s = 0; s < KS / 2; ++s) kstep(s, roff[s][0], roff[s][1]);
+                if (more) {
+                    commit_do(cur ^ 1);
+                    fetch_in(pnew);
+                }
+#pragma unroll
+                for (int s = KS / 2; s < KS; ++s) kstep(s, roff[s][0], roff[s][1]);
+            }
+            __syncthreads();                              // every wave is done reading the ring
+            if (more) commit_in(pnew, 256);
+            cur ^= 1;
+        }
+    }
+
+    const int part = blockIdx.x;
+    const int cob = co0 + coh * 32;
+    const int ci = ci0 + cih * 32 + l31;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        if (t < ntaps) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = cob + acc_row(r, h);
+                if (co < Cout && ci < Cin)
+                    a.slab[(((size_t)part * ntaps + t) * Cout + co) * Cin + ci] = acc[t][r];
+            }
+        }
+    }
+}
+
+// -1: shape not covered
+static int conv_wgrad_ring_try(const void* in, const void* dout, float* dW, const float* pro_scale, const float* pro_shift,
+                               int B, int Tin, int Tout, int V, int Cin, int Cout, int ntaps, int stride,
+                               void* ws, size_t ws_bytes, hipStream_t stream) {
+    if (Cin % 64 != 0 || Cout % 8 != 0 || V > 32 || V < 1 || ntaps > 9 || (ntaps & 1) == 0) return -1;
+    if (stride != 1 && stride != 2) return -1;
+    ConvWgradRingArgs a;
+    a.in = in; a.dout = dout; a.slab = (float*)ws; a.pro_scale = pro_scale; a.pro_shift = pro_shift;
+    a.B = B; a.Rin = Tin * V; a.Rout = Tout * V; a.V = V; a.Cin = Cin; a.Cout = Cout; a.ntaps = ntaps;
+    int ntiles;
+    if (stride == 1) { a.tile_rows = 256; ntiles = ceil_div_i(a.Rout, 256); }
+    else { const int ot = 128 / V; a.tile_rows = ot * V; ntiles = ceil_div_i(Tout, ot); }
+    a.tiles_per_sample = ntiles;
+    const int ncot = ceil_div_i(Cout, 64), ncit = Cin / 64;
+    int nwg = 256 / (ncot * ncit);
+    if (nwg < 1) nwg = 1;
+    const size_t per_part = (size_t)ntaps * Cout * Cin * sizeof(float);
+    while (nwg > 1 && (size_t)nwg * per_part > ws_bytes) nwg /= 2;
+    if ((size_t)nwg * per_part > ws_bytes) return STGCN_ERR_WORKSPACE;
+    int segs = ceil_div_i(nwg, B);                        // runs = B * segs >= nwg
+    if (segs > ntiles) segs = ntiles;
+    int tps = ceil_div_i(ntiles, segs);
+    if (tps < 4 && ntiles >= 4) tps = 4;
+    segs = ceil_div_i(ntiles, tps);
+    a.tiles_per_seg = tps; a.segs_per_sample = segs; a.nruns = B * segs;
+    if (nwg > a.nruns) nwg = a.nruns;
+    const size_t lds = 512 * 144 + 2 * (stride == 1 ? 256 : 128) * 144;
+    const void* fn = stride == 1 ? (const void*)conv_wgrad_ring_kernel<1> : (const void*)conv_wgrad_ring_kernel<2>;
+    static bool set[2] = {false, false};
+    if (!set[stride - 1]) { if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return STGCN_ERR_LAUNCH; set[stride - 1] = true; }
+    const dim3 grid((unsigned)nwg, (unsigned)ncot, (unsigned)ncit);
+    if (stride == 1) hipLaunchKernelGGL(conv_wgrad_ring_kernel<1>, grid, dim3(256), lds, stream, a);
+    else hipLaunchKernelGGL(conv_wgrad_ring_kernel<2>, grid, dim3(256), lds, stream, a);
+    if (hipGetLastError() != hipSuccess) return STGCN_ERR_LAUNCH;
+    const size_t n = (size_t)ntaps * Cout * Cin;
+    const int left = fold_parts(a.slab, nwg, n, stream);
+    hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a.slab, dW, left, ntaps, Cout, Cin);
+    return hipGetLastError() == hipSuccess ? STGCN_OK : STGCN_ERR_LAUNCH;
+}
+
 template <typename T>
 static int conv_wgrad_run(ConvWgradArgs& a, float* dW, size_t ws_bytes, hipStream_t stream) {
     constexpr int CT = 128 / ET<T>::ES;
@@ -238,6 +479,12 @@ extern "C" int stgcn_conv_wgrad(int dtype, const void* in, const void* dout, flo
     a.B = B; a.Tin = Tin; a.Tout = Tout; a.V = V; a.Cin = Cin; a.Cout = Cout;
     a.ntaps = ntaps; a.stride = stride; a.pad = pad; a.dil = dil;
     a.win_rows_max = 0; a.tiles_per_sample = 0; a.nseg = 0;
+    if (dtype == STGCN_BF16 && dil == 1 && pad == (ntaps - 1) / 2 && ntaps > 1 && B > 0 && Tin > 0 &&
+        Tout == (Tin - 1) / stride + 1) {
+        const int rc = conv_wgrad_ring_try(in, dout, dW, pro_scale, pro_shift, B, Tin, Tout, V, Cin, Cout, ntaps, stride,
+                                           workspace, workspace_bytes, (hipStream_t)stream);
+        if (rc >= 0) return rc;
+    }
     if (dtype == STGCN_BF16) return conv_wgrad_run<bf16>(a, dW, workspace_bytes, (hipStream_t)stream);
     if (dtype == STGCN_F32) return conv_wgrad_run<float>(a, dW, workspace_bytes, (hipStream_t)stream);
     return STGCN_ERR_ARG;

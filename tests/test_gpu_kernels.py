@@ -65,6 +65,9 @@ CONV_CASES = [
     (1, 64, 64, 300, 25, 9, 1, 4, True),
     (4, 128, 256, 12, 25, 1, 2, 0, False),
     (4, 256, 256, 6, 25, 9, 1, 4, True),
+    (3, 64, 128, 150, 18, 9, 2, 4, True),
+    (2, 128, 64, 61, 25, 9, 2, 4, False),
+    (3, 128, 128, 130, 25, 9, 1, 4, True),
 ]
 
 

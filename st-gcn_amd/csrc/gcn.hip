@@ -74,124 +74,193 @@ __device__ __forceinline__ void chain_mma(f32x16& accy, const f32x16& accz, cons
     }
 }
 
-template <typename T>
-__global__ __launch_bounds__(256) void gcn_fused_kernel(GcnFusedArgs a) {
+// NA = 32-byte k-steps per input row (Cin / KSTEP) as a compile-time constant, so the projection is a straight run
+// of MFMAs with its LDS reads issued ahead; NA = 0 is the any-width fallback (runtime loop, operands fetched per
+// step).  With NA <= 16 the next frame's rows are fetched into a second register set while this frame computes.
+template <typename T, int NA>
+__global__ __launch_bounds__(256, 2) void gcn_fused_kernel(GcnFusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int ES = ET<T>::ES;
     constexpr int KSTEP = ET<T>::KSTEP;
+    constexpr int VEC = ET<T>::VEC;
+    constexpr int NAP = NA == 0 ? 1 : (NA < 16 ? NA : 16);     // fragments held per pass
+    constexpr int NPASS = NA == 0 ? 0 : (NA + 15) / 16;
+    constexpr bool PF = NPASS == 1 && NA <= 8;                  // prefetch the next frame (register budget)
+    constexpr bool ONCE = NPASS == 1 && !PF;                    // fragments loaded once per frame, no prefetch
+    constexpr int NADD = 8;                                     // addend pieces prefetched per lane
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5;
-    const int V = a.V, K = a.K, Cin = a.Cin, Nout = a.Nout;
+    const int V = a.V, K = a.K, Cin = a.Cin, Nout = a.Nout, NF = a.NF;
     const int NTW = a.ntw;                       // 32-column tiles per workgroup
     const int nbase = blockIdx.y * NTW * 32;
     const int RSW = Cin * ES + 16;               // LDS row stride of the weight image
     char* wl = smem;                             // [K][NTW*32][RSW]
     char* tab = smem + (size_t)K * NTW * 32 * RSW;
     const size_t tab_k_bytes = ET<T>::IS_BF16 ? 2 * 64 * 16 : 16 * 64 * 4;
+    float* bl = (float*)(tab + (size_t)K * tab_k_bytes);        // [K][NTW*32] bias
+    const int NC = NTW * 32;
 
-    // stage weights (rows beyond Nout are zero) and the adjacency fragments
+    // stage weights (rows beyond Nout are zero), bias and the adjacency fragments
     {
         const int ppr = Cin * ES / 16;           // 16-byte pieces per row
-        const int npieces = K * NTW * 32 * ppr;
+        const int npieces = K * NC * ppr;
         for (int p = tid; p < npieces; p += 256) {
             const int seg = p % ppr, row = p / ppr;
-            const int k = row / (NTW * 32), nl = row - k * NTW * 32;
+            const int k = row / NC, nl = row - k * NC;
             const int n = nbase + nl;
             i32x4 v = zero16();
             if (n < Nout) v = *(const i32x4*)((const char*)a.w + (((size_t)k * Nout + n) * Cin) * ES + seg * 16);
             *(i32x4*)(wl + (size_t)row * RSW + seg * 16) = v;
         }
+        for (int e = tid; e < K * NC; e += 256) {
+            const int k = e / NC, n = nbase + (e - k * NC);
+            bl[e] = (a.bias && n < Nout) ? a.bias[(size_t)k * Nout + n] : 0.f;
+        }
         build_adj_chain_table<T>(tab, a.adj, K, V, tid, 256);
     }
     __syncthreads();
 
-    const int NA = Cin / KSTEP;                  // 32-byte k-steps per row
-    const int npass = (NA + 15) / 16;
-    constexpr int VEC = ET<T>::VEC;
     // per-wave output staging: [32 joints][NTW*32 channels] in the storage dtype (+16 B pad per row)
-    const int SRS = NTW * 32 * ES + 16;
-    char* stage = tab + (size_t)K * tab_k_bytes + (size_t)wave * 32 * SRS;
-    const int ppr = NTW * 32 / VEC;              // 16-byte pieces per staged row (power of two)
+    const int SRS = NC * ES + 16;
+    char* stage = (char*)(bl + (size_t)K * NC) + (size_t)wave * 32 * SRS;
+    const int ppr = NC / VEC;                    // 16-byte pieces per staged row (power of two)
     const int pshift = 31 - __builtin_clz(ppr);
     const int eseg = lane & (ppr - 1);           // this lane's fixed channel group in the store phase
-    const int ncols = min(NTW * 32, Nout - nbase);
+    const int ncols = min(NC, Nout - nbase);
+    const int npieces = V << pshift;
+    const bool col_ok = eseg * VEC < ncols;
+    const bool add_pf = a.add != nullptr && npieces <= NADD * 64;
     float st1[VEC], st2[VEC];
 #pragma unroll
     for (int i = 0; i < VEC; ++i) { st1[i] = 0.f; st2[i] = 0.f; }
+    const int brow = min(l31, V - 1);            // rows >= V duplicate the last joint; adj zeroes them
+    auto frame_ptr = [&](int f) { return (const char*)a.in + (((size_t)f * V + brow) * Cin) * ES + h * 16; };
 
-    for (int f = blockIdx.x * 4 + wave; f < a.NF; f += gridDim.x * 4) {
-        const int brow = min(l31, V - 1);        // rows >= V duplicate the last joint; adj zeroes them
-        const char* ap = (const char*)a.in + (((size_t)f * V + brow) * Cin) * ES + h * 16;
-        i32x4 afr[16];
-        auto load_a = [&](int pass) {
+    auto process = [&](int f, i32x4 (&cur)[NAP], i32x4 (&nxt)[NAP], int fnext) {
+        const char* ap = frame_ptr(f);
+        if constexpr (PF) {
+            if (fnext < NF) {
+                const char* np = frame_ptr(fnext);
 #pragma unroll
-            for (int s = 0; s < 16; ++s)
-                if (pass * 16 + s < NA) afr[s] = *(const i32x4*)(ap + (pass * 16 + s) * 32);
-        };
-        if (npass == 1) load_a(0);
+                for (int s = 0; s < NAP; ++s) nxt[s] = *(const i32x4*)(np + s * 32);
+            }
+        }
+        if constexpr (ONCE) {
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-            if (nt < NTW && nbase + nt * 32 < Nout) {
-                const int n = nbase + nt * 32 + l31;
-                f32x16 accy;
+            for (int s = 0; s < NAP; ++s) cur[s] = *(const i32x4*)(ap + s * 32);
+        }
+        i32x4 addv[NADD];
+        if (add_pf) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) accy[r] = 0.f;
-                for (int k = 0; k < K; ++k) {
-                    const float bv = (a.bias && n < Nout) ? a.bias[(size_t)k * Nout + n] : 0.f;
-                    f32x16 accz;
+            for (int i = 0; i < NADD; ++i) {
+                const int p = lane + 64 * i;
+                addv[i] = zero16();
+                if (p < npieces && col_ok)
+                    addv[i] = *(const i32x4*)((const T*)a.add + ((size_t)f * V + (p >> pshift)) * Nout + nbase + eseg * VEC);
+            }
+        }
+        for (int nt = 0; nt < NTW; ++nt) {
+            if (nbase + nt * 32 >= Nout) break;
+            f32x16 accy;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) accz[r] = bv;
-                    const char* wrow = wl + ((size_t)(k * NTW + nt) * 32 + l31) * RSW + h * 16;
-                    for (int pass = 0; pass < npass; ++pass) {
-                        if (npass > 1) load_a(pass);
+            for (int r = 0; r < 16; ++r) accy[r] = 0.f;
+            for (int k = 0; k < K; ++k) {
+                const float bv = bl[k * NC + nt * 32 + l31];
+                f32x16 accz;
 #pragma unroll
-                        for (int s = 0; s < 16; ++s) {
+                for (int r = 0; r < 16; ++r) accz[r] = bv;
+                const char* wrow = wl + ((size_t)(k * NTW + nt) * 32 + l31) * RSW + h * 16;
+                if constexpr (NA == 0) {
+                    const int nar = Cin / KSTEP;
+                    for (int s = 0; s < nar; ++s) {
+                        const i32x4 afr = *(const i32x4*)(ap + s * 32);
+                        const i32x4 bfr = *(const i32x4*)(wrow + s * 32);
+                        mma_step<T>(accz, afr, bfr);
+                    }
+                } else {
+#pragma unroll
+                    for (int pass = 0; pass < NPASS; ++pass) {
+                        if constexpr (NPASS > 1) {
+#pragma unroll
+                            for (int s = 0; s < NAP; ++s)
+                                if (pass * 16 + s < NA) cur[s] = *(const i32x4*)(ap + (pass * 16 + s) * 32);
+                        }
+#pragma unroll
+                        for (int s = 0; s < NAP; ++s) {
                             if (pass * 16 + s < NA) {
                                 const i32x4 bfr = *(const i32x4*)(wrow + (pass * 16 + s) * 32);
-                                mma_step<T>(accz, afr[s], bfr);
+                                mma_step<T>(accz, cur[s], bfr);
                             }
                         }
                     }
-                    chain_mma<T>(accy, accz, tab + (size_t)k * tab_k_bytes, lane);
                 }
-                // lane = column n, register r = joint acc_row(r, h): park the tile in the wave's staging rows
+                chain_mma<T>(accy, accz, tab + (size_t)k * tab_k_bytes, lane);
+            }
+            // lane = column n, register r = joint acc_row(r, h): park the tile in the wave's staging rows
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int aj = acc_row(r, h);
-                    if constexpr (ET<T>::IS_BF16)
-                        *(uint16_t*)(stage + aj * SRS + (nt * 32 + l31) * 2) = (uint16_t)(pack_bf16x2(accy[r], 0.f) & 0xFFFFu);
-                    else
-                        *(float*)(stage + aj * SRS + (nt * 32 + l31) * 4) = accy[r];
-                }
+            for (int r = 0; r < 16; ++r) {
+                const int aj = acc_row(r, h);
+                if constexpr (ET<T>::IS_BF16)
+                    *(uint16_t*)(stage + aj * SRS + (nt * 32 + l31) * 2) = (uint16_t)(pack_bf16x2(accy[r], 0.f) & 0xFFFFu);
+                else
+                    *(float*)(stage + aj * SRS + (nt * 32 + l31) * 4) = accy[r];
             }
         }
         __builtin_amdgcn_wave_barrier();
         // store phase: 16-byte pieces, whole channel rows coalesced; optional addend and statistics
-        const int npieces = V << pshift;
-        for (int p = lane; p < npieces; p += 64) {
+        auto emit = [&](int p, bool have, i32x4 addval) {
             const int row = p >> pshift;
-            const int col = eseg * VEC;
-            if (col < ncols) {
-                i32x4 v = *(const i32x4*)(stage + row * SRS + eseg * 16);
-                const size_t o = ((size_t)f * V + row) * Nout + nbase + col;
-                if (a.add || a.stats) {
-                    float fv[VEC];
-                    unpack16<T>(v, fv);
-                    if (a.add) {
-                        float av[VEC];
-                        unpack16<T>(*(const i32x4*)((const T*)a.add + o), av);
+            i32x4 v = *(const i32x4*)(stage + row * SRS + eseg * 16);
+            const size_t o = ((size_t)f * V + row) * Nout + nbase + eseg * VEC;
+            if (a.add || a.stats) {
+                float fv[VEC];
+                unpack16<T>(v, fv);
+                if (a.add) {
+                    float av[VEC];
+                    unpack16<T>(have ? addval : *(const i32x4*)((const T*)a.add + o), av);
 #pragma unroll
-                        for (int j = 0; j < VEC; ++j) fv[j] += av[j];
-                        v = pack16<T>(fv);
-                        if constexpr (ET<T>::IS_BF16) unpack16<T>(v, fv);      // statistics of the stored values
-                    }
-#pragma unroll
-                    for (int j = 0; j < VEC; ++j) { st1[j] += fv[j]; st2[j] += fv[j] * fv[j]; }
+                    for (int j = 0; j < VEC; ++j) fv[j] += av[j];
+                    v = pack16<T>(fv);
+                    if constexpr (ET<T>::IS_BF16) unpack16<T>(v, fv);      // statistics of the stored values
                 }
-                *(i32x4*)((T*)a.out + o) = v;
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) { st1[j] += fv[j]; st2[j] += fv[j] * fv[j]; }
+            }
+            *(i32x4*)((T*)a.out + o) = v;
+        };
+        if (col_ok) {
+            if (npieces <= NADD * 64) {
+#pragma unroll
+                for (int i = 0; i < NADD; ++i) {
+                    const int p = lane + 64 * i;
+                    if (p < npieces) emit(p, add_pf, addv[i]);
+                }
+            } else {
+                for (int p = lane; p < npieces; p += 64) emit(p, false, zero16());
             }
         }
         __builtin_amdgcn_wave_barrier();
+    };
+
+    {
+        const int fstep = gridDim.x * 4;
+        int f = blockIdx.x * 4 + wave;
+        i32x4 fa[NAP], fb[NAP];
+        if constexpr (PF) {
+            if (f < NF) {
+                const char* ap = frame_ptr(f);
+#pragma unroll
+                for (int s = 0; s < NAP; ++s) fa[s] = *(const i32x4*)(ap + s * 32);
+            }
+        }
+        while (f < NF) {
+            process(f, fa, fb, f + fstep);
+            f += fstep;
+            if (f >= NF) break;
+            if constexpr (PF) process(f, fb, fa, f + fstep);
+            else process(f, fa, fb, f + fstep);
+            f += fstep;
+        }
     }
     if (a.stats) {
         // lanes with equal eseg hold partial sums of the same channels: fold them with shuffles, then the four
@@ -205,8 +274,7 @@ __global__ __launch_bounds__(256) void gcn_fused_kernel(GcnFusedArgs a) {
             }
         }
         __syncthreads();                               // every wave is done with its staging rows
-        float* red = (float*)(tab + (size_t)K * tab_k_bytes);      // [4 waves][2][NTW*32]
-        const int NC = NTW * 32;
+        float* red = (float*)(bl + (size_t)K * NC);    // [4 waves][2][NC]
         if (lane < ppr) {
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
@@ -225,6 +293,15 @@ __global__ __launch_bounds__(256) void gcn_fused_kernel(GcnFusedArgs a) {
     }
 }
 
+template <typename T, int NA>
+static int gcn_fused_launch(GcnFusedArgs& a, dim3 grid, size_t lds, hipStream_t stream) {
+    auto kern = gcn_fused_kernel<T, NA>;
+    static bool set = false;
+    if (!set) { if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return STGCN_ERR_LAUNCH; set = true; }
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, a);
+    return hipGetLastError() == hipSuccess ? STGCN_OK : STGCN_ERR_LAUNCH;
+}
+
 template <typename T>
 static int gcn_fused_run(GcnFusedArgs& a, hipStream_t stream) {
     constexpr int ES = ET<T>::ES, KSTEP = ET<T>::KSTEP;
@@ -233,18 +310,25 @@ static int gcn_fused_run(GcnFusedArgs& a, hipStream_t stream) {
     int ntw = 4;
     while (ntw > 1 && ((size_t)a.K * ntw * 32 * rsw + adj_chain_table_bytes<T>(a.K) > 72 * 1024 || (ntw - 1) * 32 >= a.Nout)) --ntw;
     if (ntw == 3) ntw = 2;                       // the store phase wants a power-of-two piece count per row
-    const size_t lds = (size_t)a.K * ntw * 32 * rsw + adj_chain_table_bytes<T>(a.K) + (size_t)4 * 32 * (ntw * 32 * ES + 16);
+    const size_t lds = (size_t)a.K * ntw * 32 * rsw + adj_chain_table_bytes<T>(a.K) + (size_t)a.K * ntw * 32 * 4 +
+                       (size_t)4 * 32 * (ntw * 32 * ES + 16);
     if (lds > 160 * 1024) return STGCN_ERR_ARG;
     a.ntw = ntw;
     const int gy = ceil_div_i(a.Nout, ntw * 32);
-    int gx = ceil_div_i(a.NF, 4);
-    const int cap = max(1, 2048 / gy);
-    if (gx > cap) gx = cap;
-    auto kern = gcn_fused_kernel<T>;
-    static bool set = false;
-    if (!set) { if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return STGCN_ERR_LAUNCH; set = true; }
-    hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)gy), dim3(256), lds, stream, a);
-    return hipGetLastError() == hipSuccess ? STGCN_OK : STGCN_ERR_LAUNCH;
+    // persistent waves: as many workgroups as stay resident (2 per CU when the LDS image allows it)
+    const int resident = (lds <= 80 * 1024 ? 2 : 1) * 256;
+    int gx = max(1, resident / gy);
+    if (gx > ceil_div_i(a.NF, 4)) gx = ceil_div_i(a.NF, 4);
+    const dim3 grid((unsigned)gx, (unsigned)gy);
+    switch (a.Cin / KSTEP) {
+        case 1: return gcn_fused_launch<T, 1>(a, grid, lds, stream);
+        case 2: return gcn_fused_launch<T, 2>(a, grid, lds, stream);
+        case 4: return gcn_fused_launch<T, 4>(a, grid, lds, stream);
+        case 8: return gcn_fused_launch<T, 8>(a, grid, lds, stream);
+        case 16: return gcn_fused_launch<T, 16>(a, grid, lds, stream);
+        case 32: return gcn_fused_launch<T, 32>(a, grid, lds, stream);
+        default: return gcn_fused_launch<T, 0>(a, grid, lds, stream);
+    }
 }
 
 extern "C" int stgcn_gcn_fused(int dtype, const void* in, const void* w_packed, const float* adj, const float* bias,

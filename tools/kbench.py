@@ -1,0 +1,95 @@
+"""Single-kernel micro-benchmark at the shapes of the NTU training step (N=64 clips, M=2 -> B=128).
+
+    python tools/kbench.py gcn_fused:64:64 [--iters 20]
+    rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY ... -- python3 tools/kbench.py gcn_fused:64:64 --iters 3
+
+Case syntax  name:Cin:Cout[:stride]  with T derived from the channel width (64 -> 300, 128 -> 150, 256 -> 75).
+Prints mean milliseconds per launch (events on the current stream).
+"""
+import argparse
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "st-gcn_amd"))
+from stgcn_rt import ops as R  # noqa: E402
+from stgcn_rt import lib as L  # noqa: E402
+
+DEV = torch.device("cuda:0")
+V, B, K = 25, 128, 3
+
+
+def act(C, T, dtype):
+    x = torch.randn((B, C, T, V), device=DEV, dtype=torch.float32).to(dtype)
+    return x.contiguous(memory_format=torch.channels_last)
+
+
+def make(case, dtype):
+    parts = case.split(":")
+    name, Cin, Cout = parts[0], int(parts[1]), int(parts[2])
+    stride = int(parts[3]) if len(parts) > 3 else 1
+    Tin = {64: 300, 128: 150, 256: 75}.get(Cin, 300)
+    if name in ("gcn_fused", "gcn_fused_add", "gcn_agrad", "gcn_wgrad"):
+        x = act(Cin, Tin, dtype)
+        adj = torch.rand((K, V, V), device=DEV) * 0.2
+        W = torch.randn((K * Cout, Cin, 1, 1), device=DEV) * (1.0 / Cin ** 0.5)
+        bias = torch.randn((K * Cout,), device=DEV) * 0.1
+        wp = R.pack_gcn_w(W, K, Cin, dtype)
+        dy = act(Cout, Tin, dtype)
+        stats = torch.zeros(2 * Cout, dtype=torch.float64, device=DEV)
+        if name == "gcn_fused":
+            return lambda: R.gcn_fused(x, wp, adj, Cout, bias=bias, stats=stats)
+        if name == "gcn_fused_add":
+            return lambda: R.gcn_fused(x, wp, adj, Cout, add=dy)
+        if name == "gcn_agrad":
+            return lambda: R.gcn_agrad(x, wp, bias, dy)
+        return lambda: R.gcn_wgrad(x, dy, adj)
+    if name in ("conv", "conv_t", "conv_wgrad", "conv1"):
+        kt = 1 if name == "conv1" else 9
+        pad = (kt - 1) // 2
+        Tout = (Tin + 2 * pad - kt) // stride + 1
+        x = act(Cin, Tin, dtype)
+        W = torch.randn((Cout, Cin, kt, 1), device=DEV) * (1.0 / (Cin * kt) ** 0.5)
+        bias = torch.randn((Cout,), device=DEV) * 0.1
+        sc = torch.rand((Cin,), device=DEV) + 0.5
+        sh = torch.randn((Cin,), device=DEV) * 0.1
+        stats = torch.zeros(2 * Cout, dtype=torch.float64, device=DEV)
+        do = act(Cout, Tout, dtype)
+        if name in ("conv", "conv1"):
+            wp = R.pack_conv_w(W, dtype)
+            pro = (sc, sh) if kt == 9 else None
+            return lambda: R.conv_rows(x, wp, Cout, Tout, bias=bias, pro=pro, stats=stats, ntaps=kt, stride=stride, pad=pad)
+        if name == "conv_t":
+            wt = R.pack_conv_wt(W, dtype)
+            return lambda: R.conv_rows(do, wt, Cin, Tin, ntaps=kt, stride=stride, pad=pad, transposed=True)
+        return lambda: R.conv_wgrad(x, do, kt, stride, pad, pro=(sc, sh))
+    raise SystemExit("unknown case " + case)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("cases", nargs="+")
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--dtype", default="bf16")
+    a = ap.parse_args()
+    dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    L.load()
+    for case in a.cases:
+        fn = make(case, dtype)
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(a.iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        print("%-28s %8.4f ms" % (case, e0.elapsed_time(e1) / a.iters), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -13,6 +13,7 @@
 // gcn_agrad:   dA[k][v][w] = sum_{f, co} ( sum_ci W[k][co][ci] x[f,v,ci] + bias[k][co] ) * dy[f, w, co]
 // gcn_wgrad:   dW[k][co][ci] = sum_{f, v} (sum_w A_eff[k][v][w] dy[f,w,co]) * x[f, v, ci];  db[k][co] likewise.
 #include "stgcn_common.h"
+#include <type_traits>
 
 #define GCN_KMAX 3
 
@@ -350,126 +351,176 @@ struct GcnAgradArgs {
     int NF, V, Cin, Cout, K, ntw;
 };
 
-template <typename T>
-__global__ __launch_bounds__(256) void gcn_agrad_kernel(GcnAgradArgs a) {
+// NA as in gcn_fused_kernel.  Each wave keeps the K 32x32 partial dA tiles in accumulators over all its frames;
+// the four waves' tiles are summed through LDS at the end and the workgroup writes one partial to the slab.
+template <typename T, int NA>
+__global__ __launch_bounds__(256, 2) void gcn_agrad_kernel(GcnAgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int ES = ET<T>::ES;
     constexpr int KSTEP = ET<T>::KSTEP;
+    constexpr bool BF = ET<T>::IS_BF16;
+    constexpr int NAP = NA == 0 ? 1 : (NA < 16 ? NA : 16);
+    constexpr int NPASS = NA == 0 ? 0 : (NA + 15) / 16;
+    constexpr bool PF = NPASS == 1 && NA <= 8;
+    constexpr bool ONCE = NPASS == 1 && !PF;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5;
-    const int V = a.V, K = a.K, Cin = a.Cin, Cout = a.Cout;
+    const int V = a.V, K = a.K, Cin = a.Cin, Cout = a.Cout, NF = a.NF;
     const int NTW = a.ntw;
-    const int cbase = blockIdx.y * NTW * 32;
+    const int NC = NTW * 32;
+    const int cbase = blockIdx.y * NC;
     const int RSW = Cin * ES + 16;
-    char* wl = smem;                             // [K][NTW*32][RSW]
+    char* wl = smem;                             // [K][NC][RSW]
+    float* bl = (float*)(smem + (size_t)K * NC * RSW);          // [K][NC] bias
     {
         const int ppr = Cin * ES / 16;
-        const int npieces = K * NTW * 32 * ppr;
+        const int npieces = K * NC * ppr;
         for (int p = tid; p < npieces; p += 256) {
             const int seg = p % ppr, row = p / ppr;
-            const int k = row / (NTW * 32), nl = row - k * NTW * 32;
+            const int k = row / NC, nl = row - k * NC;
             const int co = cbase + nl;
             i32x4 v = zero16();
             if (co < Cout) v = *(const i32x4*)((const char*)a.w + (((size_t)k * Cout + co) * Cin) * ES + seg * 16);
             *(i32x4*)(wl + (size_t)row * RSW + seg * 16) = v;
         }
+        for (int e = tid; e < K * NC; e += 256) {
+            const int k = e / NC, co = cbase + (e - k * NC);
+            bl[e] = (a.bias && co < Cout) ? a.bias[(size_t)k * Cout + co] : 0.f;
+        }
     }
     __syncthreads();
 
-    const int NA = Cin / KSTEP;
-    const int npass = (NA + 15) / 16;
     f32x16 accd[GCN_KMAX];
 #pragma unroll
     for (int k = 0; k < GCN_KMAX; ++k)
 #pragma unroll
         for (int r = 0; r < 16; ++r) accd[k][r] = 0.f;
+    const int jrow = min(l31, V - 1);
+    auto frame_ptr = [&](int f) { return (const char*)a.x + (((size_t)f * V + jrow) * Cin) * ES + h * 16; };
+    typedef typename std::conditional<BF, i32x2, f32x4>::type dyraw_t;   // 4 consecutive channels of dy
 
-    for (int f = blockIdx.x * 4 + wave; f < a.NF; f += gridDim.x * 4) {
-        const int jrow = min(l31, V - 1);
-        const char* xp = (const char*)a.x + (((size_t)f * V + jrow) * Cin) * ES + h * 16;
-        const char* dyp = (const char*)a.dy + (((size_t)f * V + jrow) * Cout) * ES;
-        i32x4 xfr[16];
-        auto load_x = [&](int pass) {
+    auto process = [&](int f, i32x4 (&cur)[NAP], i32x4 (&nxt)[NAP], int fnext) {
+        const char* xp = frame_ptr(f);
+        if constexpr (PF) {
+            if (fnext < NF) {
+                const char* np = frame_ptr(fnext);
 #pragma unroll
-            for (int s = 0; s < 16; ++s)
-                if (pass * 16 + s < NA) xfr[s] = *(const i32x4*)(xp + (pass * 16 + s) * 32);
-        };
-        if (npass == 1) load_x(0);
+                for (int s = 0; s < NAP; ++s) nxt[s] = *(const i32x4*)(np + s * 32);
+            }
+        }
+        if constexpr (ONCE) {
+#pragma unroll
+            for (int s = 0; s < NAP; ++s) cur[s] = *(const i32x4*)(xp + s * 32);
+        }
+        // dy operand: the element for accumulator register r is dy[f, w = lane&31, c0 + acc_row(r, h)]; registers
+        // 4g..4g+3 are the 4 consecutive channels c0 + 8g + 4h + (0..3)
+        const char* dyp = (const char*)a.dy + (((size_t)f * V + jrow) * Cout) * ES;
+        dyraw_t dyr[4][4];
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
             if (nt < NTW && cbase + nt * 32 < Cout) {
-                const int c0 = cbase + nt * 32;
-                // dy operand for this co tile: element for acc register r is dy[f, w = lane, c0 + acc_row(r, h)]
-                float dyv[16];
-                if constexpr (ET<T>::IS_BF16) {
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {      // registers 4g..4g+3 are 4 consecutive channels
-                        const i32x2 raw = *(const i32x2*)(dyp + (size_t)(c0 + 8 * g + 4 * h) * 2);
-                        dyv[4 * g + 0] = __uint_as_float((uint32_t)raw[0] << 16);
-                        dyv[4 * g + 1] = __uint_as_float((uint32_t)raw[0] & 0xFFFF0000u);
-                        dyv[4 * g + 2] = __uint_as_float((uint32_t)raw[1] << 16);
-                        dyv[4 * g + 3] = __uint_as_float((uint32_t)raw[1] & 0xFFFF0000u);
-                    }
-                } else {
+                for (int g = 0; g < 4; ++g)
+                    dyr[nt][g] = *(const dyraw_t*)(dyp + (size_t)(cbase + nt * 32 + 8 * g + 4 * h) * ES);
+            }
+        }
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const f32x4 raw = *(const f32x4*)(dyp + (size_t)(c0 + 8 * g + 4 * h) * 4);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) dyv[4 * g + j] = raw[j];
-                    }
-                }
+        for (int nt = 0; nt < 4; ++nt) {
+            if (nt < NTW && cbase + nt * 32 < Cout) {
 #pragma unroll
                 for (int k = 0; k < GCN_KMAX; ++k) {
                     if (k < K) {
                         // z^T tile: rows = co (registers), cols = joint v (lane)
                         f32x16 accz;
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const int co = c0 + acc_row(r, h);
-                            accz[r] = (a.bias && co < Cout) ? a.bias[(size_t)k * Cout + co] : 0.f;
+                        for (int g = 0; g < 4; ++g) {
+                            const f32x4 b4 = *(const f32x4*)(bl + k * NC + nt * 32 + 8 * g + 4 * h);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) accz[4 * g + j] = b4[j];
                         }
                         const char* wrow = wl + ((size_t)(k * NTW + nt) * 32 + l31) * RSW + h * 16;
-                        for (int pass = 0; pass < npass; ++pass) {
-                            if (npass > 1) load_x(pass);
+                        if constexpr (NA == 0) {
+                            const int nar = Cin / KSTEP;
+                            for (int s = 0; s < nar; ++s) {
+                                const i32x4 xfr = *(const i32x4*)(xp + s * 32);
+                                const i32x4 wfr = *(const i32x4*)(wrow + s * 32);
+                                mma_step<T>(accz, wfr, xfr);
+                            }
+                        } else {
 #pragma unroll
-                            for (int s = 0; s < 16; ++s) {
-                                if (pass * 16 + s < NA) {
-                                    const i32x4 wfr = *(const i32x4*)(wrow + (pass * 16 + s) * 32);
-                                    mma_step<T>(accz, wfr, xfr[s]);
+                            for (int pass = 0; pass < NPASS; ++pass) {
+                                if constexpr (NPASS > 1) {
+#pragma unroll
+                                    for (int s = 0; s < NAP; ++s)
+                                        if (pass * 16 + s < NA) cur[s] = *(const i32x4*)(xp + (pass * 16 + s) * 32);
+                                }
+#pragma unroll
+                                for (int s = 0; s < NAP; ++s) {
+                                    if (pass * 16 + s < NA) {
+                                        const i32x4 wfr = *(const i32x4*)(wrow + (pass * 16 + s) * 32);
+                                        mma_step<T>(accz, wfr, cur[s]);
+                                    }
                                 }
                             }
                         }
                         // dA_k[v][w] += sum_co z^T[co][v] * dy[w][co]   (z^T as the A operand)
-                        if constexpr (ET<T>::IS_BF16) {
+                        if constexpr (BF) {
 #pragma unroll
                             for (int s2 = 0; s2 < 2; ++s2) {
                                 i32x4 afr, bfr;
 #pragma unroll
                                 for (int j = 0; j < 4; ++j) {
                                     afr[j] = (int)pack_bf16x2(accz[8 * s2 + 2 * j], accz[8 * s2 + 2 * j + 1]);
-                                    bfr[j] = (int)pack_bf16x2(dyv[8 * s2 + 2 * j], dyv[8 * s2 + 2 * j + 1]);
+                                    bfr[j] = dyr[nt][2 * s2 + (j >> 1)][j & 1];
                                 }
                                 accd[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(s16x8, afr), __builtin_bit_cast(s16x8, bfr), accd[k], 0, 0, 0);
                             }
                         } else {
 #pragma unroll
                             for (int r = 0; r < 16; ++r)
-                                accd[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(accz[r], dyv[r], accd[k], 0, 0, 0);
+                                accd[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(accz[r], dyr[nt][r >> 2][r & 3], accd[k], 0, 0, 0);
                         }
                     }
                 }
             }
         }
+    };
+
+    {
+        const int fstep = gridDim.x * 4;
+        int f = blockIdx.x * 4 + wave;
+        i32x4 fa[NAP], fb[NAP];
+        if constexpr (PF) {
+            if (f < NF) {
+                const char* xp = frame_ptr(f);
+#pragma unroll
+                for (int s = 0; s < NAP; ++s) fa[s] = *(const i32x4*)(xp + s * 32);
+            }
+        }
+        while (f < NF) {
+            process(f, fa, fb, f + fstep);
+            f += fstep;
+            if (f >= NF) break;
+            if constexpr (PF) process(f, fb, fa, f + fstep);
+            else process(f, fa, fb, f + fstep);
+            f += fstep;
+        }
     }
-    // accd[k]: row = v (registers), col = w (lane)
-    const size_t part = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave;
+    // accd[k]: row = v (registers), col = w (lane).  Sum the four waves through LDS, one k at a time.
+    const size_t part = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+    float* red = (float*)smem;                   // [4][16][64] floats (weights are dead now)
 #pragma unroll
     for (int k = 0; k < GCN_KMAX; ++k) {
         if (k < K) {
+            __syncthreads();
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int v = acc_row(r, h);
-                if (v < V && l31 < V) a.slab[((part * K + k) * V + v) * V + l31] = accd[k][r];
+            for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = accd[k][r];
+            __syncthreads();
+            for (int e = tid; e < 16 * 64; e += 256) {
+                const int r = e >> 6, ln = e & 63;
+                const int v = acc_row(r, ln >> 5), w = ln & 31;
+                if (v < V && w < V)
+                    a.slab[((part * K + k) * V + v) * V + w] = red[e] + red[16 * 64 + e] + red[2 * 16 * 64 + e] + red[3 * 16 * 64 + e];
             }
         }
     }
@@ -483,6 +534,15 @@ __global__ void sum_parts_kernel(const float* slab, float* out, int nparts, size
     }
 }
 
+template <typename T, int NA>
+static int gcn_agrad_launch(GcnAgradArgs& a, dim3 grid, size_t lds, hipStream_t stream) {
+    auto kern = gcn_agrad_kernel<T, NA>;
+    static bool set = false;
+    if (!set) { if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return STGCN_ERR_LAUNCH; set = true; }
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, a);
+    return hipGetLastError() == hipSuccess ? STGCN_OK : STGCN_ERR_LAUNCH;
+}
+
 template <typename T>
 static int gcn_agrad_run(GcnAgradArgs& a, float* dA, size_t ws_bytes, hipStream_t stream) {
     constexpr int ES = ET<T>::ES, KSTEP = ET<T>::KSTEP;
@@ -490,21 +550,29 @@ static int gcn_agrad_run(GcnAgradArgs& a, float* dA, size_t ws_bytes, hipStream_
     const size_t rsw = (size_t)a.Cin * ES + 16;
     int ntw = 4;
     while (ntw > 1 && ((size_t)a.K * ntw * 32 * rsw > 72 * 1024 || (ntw - 1) * 32 >= a.Cout)) --ntw;
-    const size_t lds = (size_t)a.K * ntw * 32 * rsw;
+    size_t lds = (size_t)a.K * ntw * 32 * rsw + (size_t)a.K * ntw * 32 * 4;
+    if (lds < 16 * 1024) lds = 16 * 1024;        // the final cross-wave reduction uses 16 KiB
     if (lds > 160 * 1024) return STGCN_ERR_ARG;
     a.ntw = ntw;
     const int gy = ceil_div_i(a.Cout, ntw * 32);
-    int gx = ceil_div_i(a.NF, 4);
-    const int cap = max(1, 256 / gy);
-    if (gx > cap) gx = cap;
+    const int resident = (lds <= 80 * 1024 ? 2 : 1) * 256;
+    int gx = max(1, resident / gy);
+    if (gx > ceil_div_i(a.NF, 4)) gx = ceil_div_i(a.NF, 4);
     const size_t n = (size_t)a.K * a.V * a.V;
-    if ((size_t)gx * gy * 4 * n * sizeof(float) > ws_bytes) return STGCN_ERR_WORKSPACE;
-    auto kern = gcn_agrad_kernel<T>;
-    static bool set = false;
-    if (!set) { if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return STGCN_ERR_LAUNCH; set = true; }
-    hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)gy), dim3(256), lds, stream, a);
-    if (hipGetLastError() != hipSuccess) return STGCN_ERR_LAUNCH;
-    const int left = fold_parts(a.slab, gx * gy * 4, n, stream);
+    if ((size_t)gx * gy * n * sizeof(float) > ws_bytes) return STGCN_ERR_WORKSPACE;
+    const dim3 grid((unsigned)gx, (unsigned)gy);
+    int rc;
+    switch (a.Cin / KSTEP) {
+        case 1: rc = gcn_agrad_launch<T, 1>(a, grid, lds, stream); break;
+        case 2: rc = gcn_agrad_launch<T, 2>(a, grid, lds, stream); break;
+        case 4: rc = gcn_agrad_launch<T, 4>(a, grid, lds, stream); break;
+        case 8: rc = gcn_agrad_launch<T, 8>(a, grid, lds, stream); break;
+        case 16: rc = gcn_agrad_launch<T, 16>(a, grid, lds, stream); break;
+        case 32: rc = gcn_agrad_launch<T, 32>(a, grid, lds, stream); break;
+        default: rc = gcn_agrad_launch<T, 0>(a, grid, lds, stream); break;
+    }
+    if (rc != STGCN_OK) return rc;
+    const int left = fold_parts(a.slab, gx * gy, n, stream);
     hipLaunchKernelGGL(sum_parts_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a.slab, dA, left, n);
     return hipGetLastError() == hipSuccess ? STGCN_OK : STGCN_ERR_LAUNCH;
 }

@@ -760,6 +760,230 @@ __global__ __launch_bounds__(256) void gcn_wgrad_kernel(GcnWgradArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// gcn_wgrad, bf16 wide form.  A workgroup owns a 64-channel slice of Cout and a contiguous range of frames; it
+// stages batches of FB frames (dy slice and all of x, 32 padded rows per frame) in LDS once and every wave reads
+// them from there.  A wave owns one (k, 32-wide co tile, group of `nci` 32-wide ci tiles): per frame it forms
+// dz = A_eff[k] * dy (2 MFMAs), keeps it in registers as the A operand, and adds dz^T * x into its nci accumulator
+// tiles (2 MFMAs each).  No cross-wave reduction: every (k, co, ci) element lives in exactly one wave.  The next
+// batch is fetched into registers while the current one is consumed.
+struct GcnWgradWideArgs {
+    const void* x; const void* dy; const float* adj; float* slabW; float* slabB;
+    int NF, V, Cin, Cout, K, cit, nci, FB, frames_per_wg;
+};
+
+constexpr int GW_MAXD = 2, GW_MAXX = 4;          // staged 16-byte pieces per thread per batch (dy, x)
+
+template <int NCI>
+__global__ __launch_bounds__(768) void gcn_wgrad_wide_kernel(GcnWgradWideArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, NT = blockDim.x;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int V = a.V, K = a.K, Cin = a.Cin, Cout = a.Cout, FB = a.FB;
+    constexpr int nci = NCI;
+    constexpr int DRS = 64 * 2 + 16;
+    const int XRS = Cin * 2 + 16;
+    char* tab = smem;                                     // [K][2][64] x 16 B
+    char* dimg = smem + (size_t)K * 2 * 64 * 16;          // [FB][32][DRS]
+    char* ximg = dimg + (size_t)FB * 32 * DRS;            // [FB][32][XRS] (+32 B slack for partial ci tiles)
+    const int c0 = blockIdx.y * 64;
+    const int ngrp = a.cit / nci;
+    const int cig = wave % ngrp, pair = wave / ngrp;
+    const int cot = pair & 1, k = pair >> 1;
+
+    {
+        const int nz = (int)(((size_t)FB * 32 * (DRS + XRS) + 32) / 16);
+        for (int p = tid; p < nz; p += NT) *(i32x4*)(dimg + (size_t)p * 16) = zero16();
+        for (int e = tid; e < K * 2 * 64; e += NT) {
+            const int ln = e & 63, s2 = (e >> 6) & 1, kk = e >> 7;
+            const int v = ln & 31, hh = ln >> 5;
+            float f[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int w = 16 * s2 + 8 * hh + j;
+                f[j] = (v < V && w < V) ? a.adj[((size_t)kk * V + v) * V + w] : 0.f;
+            }
+            *(i32x4*)(tab + (size_t)e * 16) = pack16<bf16>(f);
+        }
+    }
+
+    // this thread's staging pieces: piece p = tid + NT * i is segment p % ppr of batch row p / ppr; NT is a multiple
+    // of ppr, so the segment is fixed per thread and the row advances by NT / ppr per piece.  Kept per piece: the
+    // padded LDS row (frame * 32 + joint), or -1 past the batch.
+    const int dppr = 8, xppr = Cin / 8;
+    const int dseg = tid % dppr, dj0 = tid / dppr, djs = NT / dppr;
+    const int xseg = tid % xppr, xj0 = tid / xppr, xjs = NT / xppr;
+    const bool dseg_ok = c0 + dseg * 8 < Cout;
+    int d_lr[GW_MAXD], x_lr[GW_MAXX];
+#pragma unroll
+    for (int i = 0; i < GW_MAXD; ++i) {
+        const int j = dj0 + djs * i;
+        const int fi = j / V, v = j - fi * V;
+        d_lr[i] = (j < FB * V && dseg_ok) ? fi * 32 + v : -1;
+    }
+#pragma unroll
+    for (int i = 0; i < GW_MAXX; ++i) {
+        const int j = xj0 + xjs * i;
+        const int fi = j / V, v = j - fi * V;
+        x_lr[i] = j < FB * V ? fi * 32 + v : -1;
+    }
+
+    f32x16 accw[NCI];
+#pragma unroll
+    for (int it = 0; it < NCI; ++it)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accw[it][r] = 0.f;
+    float dbacc = 0.f;
+    const int q4 = (lane & 15) >> 2, p4 = lane & 3, g1 = (lane >> 4) & 1;
+    const int dcol = (cot * 32 + 16 * g1 + 4 * p4) * 2;
+    const bool active = k < K;
+
+    const int f_beg = blockIdx.x * a.frames_per_wg;
+    const int f_end = min(a.NF, f_beg + a.frames_per_wg);
+    i32x4 dreg[GW_MAXD], xreg[GW_MAXX];
+    auto fetch = [&](int f0) {
+        const int nrows = (min(f_end, f0 + FB) - f0) * V;           // valid batch rows
+        const char* dyb = (const char*)a.dy + ((size_t)f0 * V * Cout + c0 + dseg * 8) * 2;
+        const char* xb = (const char*)a.x + ((size_t)f0 * V * Cin + xseg * 8) * 2;
+#pragma unroll
+        for (int i = 0; i < GW_MAXD; ++i) {
+            const int j = dj0 + djs * i;
+            dreg[i] = zero16();
+            if (d_lr[i] >= 0 && j < nrows) dreg[i] = *(const i32x4*)(dyb + (size_t)j * Cout * 2);
+        }
+#pragma unroll
+        for (int i = 0; i < GW_MAXX; ++i) {
+            const int j = xj0 + xjs * i;
+            xreg[i] = zero16();
+            if (x_lr[i] >= 0 && j < nrows) xreg[i] = *(const i32x4*)(xb + (size_t)j * Cin * 2);
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int i = 0; i < GW_MAXD; ++i)
+            if (d_lr[i] >= 0) *(i32x4*)(dimg + d_lr[i] * DRS + dseg * 16) = dreg[i];
+#pragma unroll
+        for (int i = 0; i < GW_MAXX; ++i)
+            if (x_lr[i] >= 0) *(i32x4*)(ximg + x_lr[i] * XRS + xseg * 16) = xreg[i];
+    };
+
+    if (f_beg < f_end) fetch(f_beg);
+    for (int f0 = f_beg; f0 < f_end; f0 += FB) {
+        __syncthreads();                                  // images of the previous batch fully consumed (and the zero fill)
+        commit();
+        __syncthreads();
+        if (f0 + FB < f_end) fetch(f0 + FB);
+        if (active) {
+            const int nfr = min(FB, f_end - f0);
+            for (int fi = 0; fi < nfr; ++fi) {
+                const char* di = dimg + (size_t)fi * 32 * DRS;
+                const char* xi = ximg + (size_t)fi * 32 * XRS;
+                // dz = A_eff[k] (v x w) * dy (w x co): rows = v (registers), cols = co (lane)
+                f32x16 dz;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dz[r] = 0.f;
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const i32x4 afr = *(const i32x4*)(tab + (((size_t)k * 2 + s2) * 64 + lane) * 16);
+                    const int row0 = 16 * s2 + 8 * h + q4;
+                    const s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(di + row0 * DRS + dcol));
+                    const s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(di + (row0 + 4) * DRS + dcol));
+                    const s16x8 bfr = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+                    dz = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(s16x8, afr), bfr, dz, 0, 0, 0);
+                }
+                float sdz = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sdz += dz[r];
+                dbacc += sdz;
+                // dW_k[co][ci] += sum_v dz[v][co] * x[v][ci]   (dz as the A operand, contraction in acc-row order)
+                i32x4 afr2[2];
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) afr2[s2][j] = (int)pack_bf16x2(dz[8 * s2 + 2 * j], dz[8 * s2 + 2 * j + 1]);
+#pragma unroll
+                for (int it = 0; it < NCI; ++it) {
+                    {
+                        const int col = ((cig * nci + it) * 32 + 16 * g1 + 4 * p4) * 2;
+#pragma unroll
+                        for (int s2 = 0; s2 < 2; ++s2) {
+                            const int row0 = 16 * s2 + 4 * h + q4;
+                            const s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(xi + row0 * XRS + col));
+                            const s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(xi + (row0 + 8) * XRS + col));
+                            const s16x8 bfr = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+                            accw[it] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(s16x8, afr2[s2]), bfr, accw[it], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        }
+    }
+
+    if (active) {
+        const size_t part = blockIdx.x;
+#pragma unroll
+        for (int it = 0; it < NCI; ++it) {
+            {
+                const int ci = (cig * nci + it) * 32 + l31;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = c0 + cot * 32 + acc_row(r, h);
+                    if (co < Cout && ci < Cin) a.slabW[((part * K + k) * Cout + co) * Cin + ci] = accw[it][r];
+                }
+            }
+        }
+        const float sb = dbacc + __shfl_xor(dbacc, 32);
+        const int co = c0 + cot * 32 + l31;
+        if (a.slabB && cig == 0 && h == 0 && co < Cout) a.slabB[(part * K + k) * Cout + co] = sb;
+    }
+}
+
+// -1: shape outside the wide kernel's domain
+static int gcn_wgrad_wide_try(const void* x, const void* dy, const float* adj, float* dW, float* db,
+                              int NF, int V, int Cin, int Cout, int K, void* ws, size_t ws_bytes, hipStream_t stream) {
+    const int cit = ceil_div_i(Cin, 32);
+    if (!(cit == 1 || cit == 2 || cit == 4 || cit == 8) || Cin % 8 != 0 || Cout % 8 != 0 || K < 1 || K > GCN_KMAX || V < 1 || V > 32) return -1;
+    GcnWgradWideArgs a;
+    a.x = x; a.dy = dy; a.adj = adj; a.NF = NF; a.V = V; a.Cin = Cin; a.Cout = Cout; a.K = K;
+    a.cit = cit; a.nci = cit >= 2 ? cit / 2 : 1;
+    const int nw = K * 2 * (cit / a.nci);
+    const int nt = nw * 64;
+    const size_t per_frame = (size_t)32 * (144 + Cin * 2 + 16);
+    int fb = 8;
+    while (fb > 1 && ((size_t)fb * per_frame > 120 * 1024 || ceil_div_i(fb * V * 8, nt) > GW_MAXD || ceil_div_i(fb * V * (Cin / 8), nt) > GW_MAXX)) --fb;
+    if (ceil_div_i(fb * V * 8, nt) > GW_MAXD || ceil_div_i(fb * V * (Cin / 8), nt) > GW_MAXX) return -1;
+    a.FB = fb;
+    const size_t lds = (size_t)K * 2 * 64 * 16 + (size_t)fb * per_frame + 32;
+    if (lds > 160 * 1024) return -1;
+    const int gy = ceil_div_i(Cout, 64);
+    int gx = max(1, 256 / gy);
+    const size_t nW = (size_t)K * Cout * Cin, nB = (size_t)K * Cout;
+    while (gx > 1 && (size_t)gx * (nW + nB) * sizeof(float) > ws_bytes) gx /= 2;
+    if ((size_t)gx * (nW + nB) * sizeof(float) > ws_bytes) return STGCN_ERR_WORKSPACE;
+    int fpw = ceil_div_i(NF, gx);
+    fpw = ceil_div_i(fpw, fb) * fb;
+    gx = ceil_div_i(NF, fpw);
+    a.frames_per_wg = fpw;
+    a.slabW = (float*)ws;
+    a.slabB = db ? a.slabW + (size_t)gx * nW : nullptr;
+    const void* fn = a.nci == 1 ? (const void*)gcn_wgrad_wide_kernel<1> : a.nci == 2 ? (const void*)gcn_wgrad_wide_kernel<2> : (const void*)gcn_wgrad_wide_kernel<4>;
+    static bool set[3] = {false, false, false};
+    const int si = a.nci == 1 ? 0 : a.nci == 2 ? 1 : 2;
+    if (!set[si]) { if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return STGCN_ERR_LAUNCH; set[si] = true; }
+    const dim3 grid((unsigned)gx, (unsigned)gy), block((unsigned)nt);
+    if (a.nci == 1) hipLaunchKernelGGL(gcn_wgrad_wide_kernel<1>, grid, block, lds, stream, a);
+    else if (a.nci == 2) hipLaunchKernelGGL(gcn_wgrad_wide_kernel<2>, grid, block, lds, stream, a);
+    else hipLaunchKernelGGL(gcn_wgrad_wide_kernel<4>, grid, block, lds, stream, a);
+    if (hipGetLastError() != hipSuccess) return STGCN_ERR_LAUNCH;
+    const int leftW = fold_parts(a.slabW, gx, nW, stream);
+    hipLaunchKernelGGL(sum_parts_kernel, dim3((unsigned)((nW + 255) / 256)), dim3(256), 0, stream, a.slabW, dW, leftW, nW);
+    if (db) {
+        const int leftB = fold_parts(a.slabB, gx, nB, stream);
+        hipLaunchKernelGGL(sum_parts_kernel, dim3((unsigned)((nB + 255) / 256)), dim3(256), 0, stream, a.slabB, db, leftB, nB);
+    }
+    return hipGetLastError() == hipSuccess ? STGCN_OK : STGCN_ERR_LAUNCH;
+}
+
 template <typename T>
 static int gcn_wgrad_run(GcnWgradArgs& a, float* dW, float* db, size_t ws_bytes, hipStream_t stream) {
     constexpr int ES = ET<T>::ES, KSTEP = ET<T>::KSTEP;
@@ -803,6 +1027,10 @@ extern "C" int stgcn_gcn_wgrad(int dtype, const void* x, const void* dy, const f
     GcnWgradArgs a;
     a.x = x; a.dy = dy; a.adj = adj; a.slabW = (float*)workspace; a.slabB = nullptr;
     a.NF = NF; a.V = V; a.Cin = Cin; a.Cout = Cout; a.K = K; a.cig = 0; a.iters = 0;
+    if (dtype == STGCN_BF16 && NF > 0) {
+        const int rc = gcn_wgrad_wide_try(x, dy, adj, dW, db, NF, V, Cin, Cout, K, workspace, workspace_bytes, (hipStream_t)stream);
+        if (rc >= 0) return rc;
+    }
     if (dtype == STGCN_BF16) return gcn_wgrad_run<bf16>(a, dW, db, workspace_bytes, (hipStream_t)stream);
     if (dtype == STGCN_F32) return gcn_wgrad_run<float>(a, dW, db, workspace_bytes, (hipStream_t)stream);
     return STGCN_ERR_ARG;

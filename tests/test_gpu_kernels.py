@@ -158,6 +158,8 @@ GCN_DIRECT = [
     ("ntu-rgb+d", "spatial", True, 1, 128, 256, 7),
     ("ntu-rgb+d", "spatial", False, 4, 128, 256, 12),
     ("ntu-rgb+d", "spatial", False, 4, 256, 256, 6),
+    ("ntu-rgb+d", "spatial", True, 4, 48, 80, 600),      # odd widths (any-width paths), several batches per workgroup
+    ("openpose", "distance", True, 3, 64, 64, 301),
 ]
 
 

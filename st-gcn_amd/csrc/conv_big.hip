@@ -1,0 +1,374 @@
+// conv_big: bf16 temporal convolutions that the LDS-ring kernel (conv_t9) does not take -- 256 input channels,
+// stride 2 in either direction, the 1-tap strided residual convolution -- as a persistent tiled implicit GEMM.
+//
+// Same arithmetic as conv_rows (see conv_rows.hip).  Every supported form is expressed over VIRTUAL output
+// frames j of one sample:
+//     real output frame = os * j + opar,      input frame of effective tap i = fs * j + foff[i],   weights wk[i]
+//   forward, stride s        : fs = s, os = 1,            foff[i] = i - pad,             wk[i] = i
+//   transposed, stride 1     : fs = 1, os = 1,            foff[i] = pad - i,             wk[i] = i
+//   transposed, stride 2     : one launch per output-frame parity p (os = 2, opar = p, fs = 1) with only the taps k
+//                              of matching parity: foff = (p + pad - k) / 2.  No MFMA is spent on the zeros a
+//                              strided transposed convolution is full of; a parity without taps writes zeros.
+//
+//   - A workgroup (4 waves) owns one 128-channel tile of Cout and walks (sample, row-tile) pairs; a row tile is
+//     BM = 256 (or 128) virtual output rows.  Per 64-channel chunk of Cin the window of input rows all taps need is
+//     staged once in LDS (BatchNorm+ReLU prologue applied once per element); taps read their A fragments from it at
+//     per-lane row offsets (a zero row stands in for frames outside the sample).
+//   - The NEXT window (next chunk, or the first chunk of the next tile) is fetched into registers while the current
+//     chunk's taps run, so global latency hides under 9 x 16 (or 32) MFMAs per wave; weight tiles (128 x 64 per
+//     tap) are double-buffered the same way.
+//   - Per wave 64 rows x 128 channels (BM = 256: 6 LDS fragment reads per 8 MFMAs) or 64 x 64 (BM = 128).
+//   - Epilogue: accumulators (+bias) are rounded to bf16 into LDS, then leave as 16-byte row pieces: coalesced
+//     stores, coalesced loads of the auxiliary tensor of the fused ReLU/BatchNorm backward, per-thread statistics
+//     (fixed channels) that reach memory as one double atomic per channel per workgroup.
+#include "stgcn_common.h"
+
+struct ConvBigArgs {
+    const void* in; const void* w; void* out;
+    const float* bias; const float* pro_scale; const float* pro_shift;
+    const void* aux; const float* ep_scale; const float* ep_shift; const float* ep_mean; const float* ep_rstd;
+    double* stats;
+    int B, Tin, V, Cin, Cout;
+    int Tv, Tout_real;
+    int fs, os, opar, ntaps;
+    int foff[9], wk[9];
+    int foff_min, foff_max;
+    int tiles_per_sample, zero_row;
+};
+
+constexpr int CB_RS = 144;
+constexpr int CB_NPF = 17;          // window pieces per thread: up to 544 window rows
+constexpr int CB_BN = 128;
+
+template <int WR, int WC, int MT, int NT, int EPI>
+__global__ __launch_bounds__(256) void conv_big_kernel(ConvBigArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int BM = WR * MT * 32;
+    static_assert(WC * NT * 32 == CB_BN, "column tile is 128");
+    constexpr int SRS = CB_BN * 2 + 16;                  // epilogue staging row stride
+    char* win = smem;
+    char* wbuf = smem + (size_t)CB_NPF * 32 * CB_RS;     // 2 x [128][RS]
+    const int ZOFF = a.zero_row * CB_RS;                 // byte offset of the all-zero row
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wr = wave % WR, wc = wave / WR;
+    const int V = a.V, Cin = a.Cin, Cout = a.Cout, Tin = a.Tin, ntaps = a.ntaps;
+    const int co0 = blockIdx.y * CB_BN;
+    const int Rv = a.Tv * V, Rreal = a.Tout_real * V;
+    const int nchunks = Cin / 64;
+    const int ntile_total = a.B * a.tiles_per_sample;
+
+    if (tid < CB_RS / 16) *(i32x4*)(smem + ZOFF + tid * 16) = zero16();
+
+    const int sseg = tid & 7, srow = tid >> 3;           // window staging: 32 rows per pass
+    const int eseg = tid & 15, erow = tid >> 4;          // epilogue: 16 rows per pass, fixed 8 channels
+    const bool has_pro = a.pro_scale != nullptr;
+
+    float e_sc[8], e_sh[8], e_mu[8], e_rs[8], s1[8], s2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        s1[j] = 0.f; s2[j] = 0.f;
+        const int co = co0 + eseg * 8 + j;
+        if (EPI == 1 && co < Cout) { e_sc[j] = a.ep_scale[co]; e_sh[j] = a.ep_shift[co]; e_mu[j] = a.ep_mean[co]; e_rs[j] = a.ep_rstd[co]; }
+        else { e_sc[j] = e_sh[j] = e_mu[j] = e_rs[j] = 0.f; }
+    }
+    float biasv[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const int co = co0 + (wc * NT + n) * 32 + l31;
+        biasv[n] = (a.bias && co < Cout) ? a.bias[co] : 0.f;
+    }
+
+    // tile geometry
+    auto tile_geo = [&](int ti, int& b, int& r0, int& r1, int& flo, int& wrows) {
+        b = ti / a.tiles_per_sample;
+        const int tile = ti - b * a.tiles_per_sample;
+        r0 = tile * BM;
+        r1 = min(r0 + BM, Rv);
+        const int tlo = r0 / V, thi = (r1 - 1) / V;
+        int f0 = a.fs * tlo + a.foff_min, f1 = a.fs * thi + a.foff_max;
+        f0 = max(f0, 0);
+        f1 = min(f1, Tin - 1);
+        flo = f0;
+        wrows = max(0, (f1 - f0 + 1) * V);
+    };
+    i32x4 pf[CB_NPF];
+    auto fetch_win = [&](int b, int flo, int wrows, int chunk) {
+        const char* base = (const char*)a.in + (((size_t)b * Tin + flo) * V * (size_t)Cin + (size_t)chunk * 64 + sseg * 8) * 2;
+#pragma unroll
+        for (int i = 0; i < CB_NPF; ++i) {
+            const int row = srow + 32 * i;
+            if (row < wrows) pf[i] = *(const i32x4*)(base + (size_t)row * Cin * 2);
+        }
+    };
+    auto commit_win = [&](int wrows, int chunk) {
+        float psc[8], psh[8];
+        if (has_pro) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { psc[j] = a.pro_scale[chunk * 64 + sseg * 8 + j]; psh[j] = a.pro_shift[chunk * 64 + sseg * 8 + j]; }
+        }
+#pragma unroll
+        for (int i = 0; i < CB_NPF; ++i) {
+            const int row = srow + 32 * i;
+            if (row < wrows) {
+                i32x4 v = pf[i];
+                if (has_pro) {
+                    float f[8];
+                    unpack16<bf16>(v, f);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) f[j] = fmaxf(fmaf(f[j], psc[j], psh[j]), 0.f);
+                    v = pack16<bf16>(f);
+                }
+                *(i32x4*)(win + (size_t)row * CB_RS + sseg * 16) = v;
+            }
+        }
+    };
+    i32x4 wreg[4];
+    auto load_w = [&](int chunk, int tapi) {
+        const int tap = a.wk[tapi];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int p = tid + 256 * i;
+            const int n = p >> 3, sg = p & 7;
+            const int co = co0 + n;
+            wreg[i] = zero16();
+            if (co < Cout) wreg[i] = *(const i32x4*)((const uint16_t*)a.w + ((size_t)tap * Cout + co) * Cin + chunk * 64 + sg * 8);
+        }
+    };
+    auto store_w = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int p = tid + 256 * i;
+            *(i32x4*)(wbuf + (size_t)buf * CB_BN * CB_RS + (p >> 3) * CB_RS + (p & 7) * 16) = wreg[i];
+        }
+    };
+
+    int ti = blockIdx.x;
+    if (ti >= ntile_total) return;
+    int b, r0, r1, flo, wrows;
+    tile_geo(ti, b, r0, r1, flo, wrows);
+    if (ntaps > 0) { fetch_win(b, flo, wrows, 0); load_w(0, 0); }
+    int wpar = 0;                                          // weight buffer parity
+
+    for (; ti < ntile_total; ti += gridDim.x) {
+        // this lane's output rows (one per row subtile)
+        int t_out[MT], vj[MT];
+        bool rvalid[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int u = r0 + (wr * MT + m) * 32 + l31;
+            rvalid[m] = u < r1;
+            const int uu = rvalid[m] ? u : r0;
+            t_out[m] = uu / V;
+            vj[m] = uu - t_out[m] * V;
+        }
+        f32x16 acc[MT][NT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+        // geometry of the next tile (its first window is prefetched during this tile's last chunk)
+        const int tn = ti + gridDim.x;
+        int nb = 0, nr0 = 0, nr1 = 0, nflo = 0, nwrows = 0;
+        if (tn < ntile_total) tile_geo(tn, nb, nr0, nr1, nflo, nwrows);
+
+        if (ntaps > 0) {
+            for (int chunk = 0; chunk < nchunks; ++chunk) {
+                __syncthreads();                           // previous window / epilogue staging fully consumed
+                commit_win(wrows, chunk);
+                if (chunk + 1 < nchunks) fetch_win(b, flo, wrows, chunk + 1);
+                else if (tn < ntile_total) fetch_win(nb, nflo, nwrows, 0);
+                for (int tapi = 0; tapi < ntaps; ++tapi) {
+                    store_w(wpar);
+                    __syncthreads();
+                    // next weight tile: next tap, next chunk, or the first of the next tile
+                    if (tapi + 1 < ntaps) load_w(chunk, tapi + 1);
+                    else if (chunk + 1 < nchunks) load_w(chunk + 1, 0);
+                    else if (tn < ntile_total) load_w(0, 0);
+                    int aoff[MT];
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) {
+                        const int fr = a.fs * t_out[m] + a.foff[tapi];
+                        const bool ok = rvalid[m] && fr >= 0 && fr < Tin;
+                        aoff[m] = (ok ? ((fr - flo) * V + vj[m]) * CB_RS : ZOFF) + h * 16;
+                    }
+                    const char* wb = wbuf + (size_t)wpar * CB_BN * CB_RS + ((wc * NT) * 32 + l31) * CB_RS + h * 16;
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        i32x4 af[MT];
+#pragma unroll
+                        for (int m = 0; m < MT; ++m) af[m] = *(const i32x4*)(win + aoff[m] + s * 32);
+#pragma unroll
+                        for (int n = 0; n < NT; ++n) {
+                            const i32x4 bf = *(const i32x4*)(wb + n * 32 * CB_RS + s * 32);
+#pragma unroll
+                            for (int m = 0; m < MT; ++m) mma_step<bf16>(acc[m][n], af[m], bf);
+                        }
+                    }
+                    wpar ^= 1;
+                }
+            }
+        }
+        __syncthreads();                                   // every wave is done with the window and weight tiles
+
+        // accumulators (+bias) -> bf16 -> staging rows
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int rl = (wr * MT + m) * 32 + acc_row(r, h);
+                    const int col = (wc * NT + n) * 32 + l31;
+                    const uint32_t pk = pack_bf16x2(acc[m][n][r] + biasv[n], 0.f);
+                    *(uint16_t*)(smem + (size_t)rl * SRS + col * 2) = (uint16_t)(pk & 0xFFFFu);
+                }
+        __syncthreads();
+        {
+            const bool cok = co0 + eseg * 8 < Cout;
+            const uint16_t* auxb = (const uint16_t*)a.aux + (size_t)b * Rreal * Cout + co0 + eseg * 8;
+            uint16_t* outb = (uint16_t*)a.out + (size_t)b * Rreal * Cout + co0 + eseg * 8;
+#pragma unroll 1
+            for (int g = 0; g < BM / 128; ++g) {
+                int rrow[8];
+                i32x4 av[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int u = r0 + erow + 16 * (g * 8 + i);
+                    int rr = -1;
+                    if (u < r1 && cok) {
+                        if (a.os == 1) rr = u;
+                        else { const int t = u / V; rr = (a.os * t + a.opar) * V + (u - t * V); }
+                    }
+                    rrow[i] = rr;
+                    if constexpr (EPI == 1) {
+                        av[i] = zero16();
+                        if (rr >= 0) av[i] = *(const i32x4*)(auxb + (size_t)rr * Cout);
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    if (rrow[i] >= 0) {
+                        const int rl = erow + 16 * (g * 8 + i);
+                        i32x4 v = *(const i32x4*)(smem + (size_t)rl * SRS + eseg * 16);
+                        float f[8];
+                        unpack16<bf16>(v, f);
+                        if constexpr (EPI == 1) {
+                            float y[8];
+                            unpack16<bf16>(av[i], y);
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) {
+                                f[j] = (fmaf(y[j], e_sc[j], e_sh[j]) > 0.f) ? f[j] : 0.f;
+                                s1[j] += f[j];
+                                s2[j] += f[j] * ((y[j] - e_mu[j]) * e_rs[j]);
+                            }
+                            v = pack16<bf16>(f);
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) { s1[j] += f[j]; s2[j] += f[j] * f[j]; }
+                        }
+                        *(i32x4*)(outb + (size_t)rrow[i] * Cout) = v;
+                    }
+                }
+            }
+        }
+        b = nb; r0 = nr0; r1 = nr1; flo = nflo; wrows = nwrows;
+    }
+
+    if (a.stats) {
+        __syncthreads();
+        float* red = (float*)smem;                        // [256][16]
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { red[tid * 16 + j] = s1[j]; red[tid * 16 + 8 + j] = s2[j]; }
+        __syncthreads();
+        {
+            const int which = tid >> 7, c = tid & 127;    // which: 0 = s1, 1 = s2 ; c = channel within the tile
+            const int sg = c >> 3, j = c & 7;
+            float t = 0.f;
+            for (int r = 0; r < 16; ++r) t += red[(r * 16 + sg) * 16 + which * 8 + j];
+            if (co0 + c < Cout) atomicAdd(&a.stats[which * Cout + co0 + c], (double)t);
+        }
+    }
+}
+
+template <int WR, int WC, int MT, int NT, int EPI>
+static int launch_conv_big(ConvBigArgs& a, hipStream_t stream) {
+    constexpr int BM = WR * MT * 32;
+    a.tiles_per_sample = ceil_div_i(a.Tv * a.V, BM);
+    const size_t body = (size_t)CB_NPF * 32 * CB_RS + 2 * (size_t)CB_BN * CB_RS;
+    a.zero_row = (int)((body + CB_RS - 1) / CB_RS);
+    const size_t lds = (size_t)(a.zero_row + 1) * CB_RS;
+    const int nct = ceil_div_i(a.Cout, CB_BN);
+    int gx = max(1, 256 / nct);
+    if (gx > a.B * a.tiles_per_sample) gx = a.B * a.tiles_per_sample;
+    auto kern = conv_big_kernel<WR, WC, MT, NT, EPI>;
+    static bool set = false;
+    if (!set) { if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return STGCN_ERR_LAUNCH; set = true; }
+    hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)nct), dim3(256), lds, stream, a);
+    return hipGetLastError() == hipSuccess ? STGCN_OK : STGCN_ERR_LAUNCH;
+}
+
+// window rows a tile of BM virtual rows can need
+static int conv_big_win_rows(const ConvBigArgs& a, int BM) {
+    const int nf = (BM - 2) / a.V + 2;
+    int fr = a.fs * (nf - 1) + (a.foff_max - a.foff_min) + 1;
+    if (fr > a.Tin) fr = a.Tin;
+    return fr * a.V;
+}
+
+// dry = true: only report whether the shape fits (0) or not (-1)
+static int conv_big_launch_any(ConvBigArgs& a, int epi, hipStream_t stream, bool dry) {
+    a.foff_min = 0; a.foff_max = 0;
+    for (int i = 0; i < a.ntaps; ++i) {
+        if (i == 0 || a.foff[i] < a.foff_min) a.foff_min = a.foff[i];
+        if (i == 0 || a.foff[i] > a.foff_max) a.foff_max = a.foff[i];
+    }
+    const int Rv = a.Tv * a.V;
+    // 256-row tiles read fewer fragments per MFMA; 128-row tiles waste less on the ragged last tile of a sample
+    const double waste256 = 1.0 - (double)Rv / (ceil_div_i(Rv, 256) * 256.0);
+    const double waste128 = 1.0 - (double)Rv / (ceil_div_i(Rv, 128) * 128.0);
+    const bool fit256 = conv_big_win_rows(a, 256) <= CB_NPF * 32;
+    const bool fit128 = conv_big_win_rows(a, 128) <= CB_NPF * 32;
+    if (dry) return (fit256 || fit128) ? 0 : -1;
+    if (fit256 && (waste256 <= waste128 + 0.04 || !fit128))
+        return epi == 1 ? launch_conv_big<4, 1, 2, 4, 1>(a, stream) : launch_conv_big<4, 1, 2, 4, 0>(a, stream);
+    if (fit128)
+        return epi == 1 ? launch_conv_big<2, 2, 2, 2, 1>(a, stream) : launch_conv_big<2, 2, 2, 2, 0>(a, stream);
+    return -1;
+}
+
+// Returns -1 when the shape is outside this kernel's domain (the caller then uses conv_rows).
+int conv_big_try(const void* in, const void* w, void* out, const float* bias, const float* pro_scale, const float* pro_shift,
+                 int epilogue, const void* aux, const float* ep_scale, const float* ep_shift, const float* ep_mean, const float* ep_rstd,
+                 double* stats, int B, int Tin, int Tout, int V, int Cin, int Cout, int ntaps, int stride, int pad, int dil,
+                 int transposed, hipStream_t stream) {
+    if (Cin % 64 != 0 || Cin <= 0 || Cout % 8 != 0 || V < 1 || V > 32 || ntaps < 1 || ntaps > 9 || dil != 1 || (stride != 1 && stride != 2)) return -1;
+    ConvBigArgs a;
+    a.in = in; a.w = w; a.out = out; a.bias = bias; a.pro_scale = pro_scale; a.pro_shift = pro_shift;
+    a.aux = aux; a.ep_scale = ep_scale; a.ep_shift = ep_shift; a.ep_mean = ep_mean; a.ep_rstd = ep_rstd; a.stats = stats;
+    a.B = B; a.Tin = Tin; a.V = V; a.Cin = Cin; a.Cout = Cout; a.Tout_real = Tout;
+    a.tiles_per_sample = 0; a.zero_row = 0;
+    if (!transposed || stride == 1) {
+        a.fs = transposed ? 1 : stride; a.os = 1; a.opar = 0; a.Tv = Tout; a.ntaps = ntaps;
+        for (int i = 0; i < ntaps; ++i) { a.foff[i] = transposed ? pad - i : i - pad; a.wk[i] = i; }
+        return conv_big_launch_any(a, epilogue, stream, false);
+    }
+    // transposed, stride 2: one launch per output-frame parity
+    for (int pass = 0; pass < 2; ++pass) {               // pass 0 checks both parities fit, pass 1 launches
+        for (int par = 0; par < 2; ++par) {
+            a.fs = 1; a.os = 2; a.opar = par; a.Tv = (Tout - par + 1) / 2; a.ntaps = 0;
+            if (a.Tv <= 0) continue;
+            for (int k = 0; k < ntaps; ++k) {
+                const int num = par + pad - k;
+                if ((num & 1) == 0) { a.foff[a.ntaps] = num / 2; a.wk[a.ntaps] = k; ++a.ntaps; }
+            }
+            const int rc = conv_big_launch_any(a, epilogue, stream, pass == 0);
+            if (rc != STGCN_OK) return rc;
+        }
+    }
+    return STGCN_OK;
+}

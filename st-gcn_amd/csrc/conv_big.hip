@@ -36,6 +36,8 @@ struct ConvBigArgs {
     int tiles_per_sample, zero_row;
 };
 
+// scheduling pattern for one k-step: NR LDS reads paired two-by-two behind the first MFMAs, then the remaining MFMAs
+#define CB_INTERLEAVE(NR, NM) _Pragma("unroll") for (int i_ = 0; i_ < (NR) / 2; ++i_) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); } __builtin_amdgcn_sched_group_barrier(0x008, (NM) - (NR) / 2, 0);
 constexpr int CB_RS = 144;
 constexpr int CB_NPF = 17;          // window pieces per thread: up to 544 window rows
 constexpr int CB_BN = 128;
@@ -47,7 +49,7 @@ __global__ __launch_bounds__(256) void conv_big_kernel(ConvBigArgs a) {
     static_assert(WC * NT * 32 == CB_BN, "column tile is 128");
     constexpr int SRS = CB_BN * 2 + 16;                  // epilogue staging row stride
     char* win = smem;
-    char* wbuf = smem + (size_t)CB_NPF * 32 * CB_RS;     // 2 x [128][RS]
+    char* wbuf = smem + (size_t)CB_NPF * 32 * CB_RS;     // 3 x [128][RS]
     const int ZOFF = a.zero_row * CB_RS;                 // byte offset of the all-zero row
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -144,12 +146,26 @@ __global__ __launch_bounds__(256) void conv_big_kernel(ConvBigArgs a) {
         }
     };
 
+    // Weight tiles cycle through three LDS buffers.  Tile g of the (chunk-major, then tap) sequence -- the same for
+    // every row tile of this workgroup, so it just wraps around -- is fetched to registers during step g-3, stored
+    // to buffer g % 3 during step g-2, published by the barrier that opens step g-1, and read during step g; its
+    // first fragments are already read at the end of step g-1.
+    int wi_chunk = 0, wi_tap = 0;                          // iterator of the next tile to fetch
+    auto load_w_next = [&]() {
+        load_w(wi_chunk, wi_tap);
+        if (++wi_tap == ntaps) { wi_tap = 0; if (++wi_chunk == nchunks) wi_chunk = 0; }
+    };
     int ti = blockIdx.x;
     if (ti >= ntile_total) return;
     int b, r0, r1, flo, wrows;
     tile_geo(ti, b, r0, r1, flo, wrows);
-    if (ntaps > 0) { fetch_win(b, flo, wrows, 0); load_w(0, 0); }
-    int wpar = 0;                                          // weight buffer parity
+    if (ntaps > 0) {
+        fetch_win(b, flo, wrows, 0);
+        load_w_next(); store_w(0);
+        load_w_next(); store_w(1);
+        load_w_next();
+    }
+    int wcur = 0;                                          // buffer of the current step's weight tile
 
     for (; ti < ntile_total; ti += gridDim.x) {
         // this lane's output rows (one per row subtile)
@@ -177,43 +193,83 @@ __global__ __launch_bounds__(256) void conv_big_kernel(ConvBigArgs a) {
         if (tn < ntile_total) tile_geo(tn, nb, nr0, nr1, nflo, nwrows);
 
         if (ntaps > 0) {
+            struct Frag { i32x4 af[MT]; i32x4 bf[NT]; };
+            auto a_offsets = [&](int tapi, int (&aoff)[MT]) {
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    const int fr = a.fs * t_out[m] + a.foff[tapi];
+                    const bool ok = rvalid[m] && fr >= 0 && fr < Tin;
+                    aoff[m] = (ok ? ((fr - flo) * V + vj[m]) * CB_RS : ZOFF) + h * 16;
+                }
+            };
+            auto load_frag = [&](Frag& f, const int (&aoff)[MT], int wbi, int s) {
+                const char* wb = wbuf + (size_t)wbi * CB_BN * CB_RS + ((wc * NT) * 32 + l31) * CB_RS + h * 16;
+#pragma unroll
+                for (int m = 0; m < MT; ++m) f.af[m] = *(const i32x4*)(win + aoff[m] + s * 32);
+#pragma unroll
+                for (int n = 0; n < NT; ++n) f.bf[n] = *(const i32x4*)(wb + n * 32 * CB_RS + s * 32);
+            };
+            auto mma_frag = [&](const Frag& f) {
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) mma_step<bf16>(acc[m][n], f.af[m], f.bf[n]);
+            };
+            Frag fa, fb;
+            int aoff[MT], aoff_n[MT];
             for (int chunk = 0; chunk < nchunks; ++chunk) {
-                __syncthreads();                           // previous window / epilogue staging fully consumed
+                lds_barrier();                             // previous window / epilogue staging fully consumed
                 commit_win(wrows, chunk);
                 if (chunk + 1 < nchunks) fetch_win(b, flo, wrows, chunk + 1);
                 else if (tn < ntile_total) fetch_win(nb, nflo, nwrows, 0);
                 for (int tapi = 0; tapi < ntaps; ++tapi) {
-                    store_w(wpar);
-                    __syncthreads();
-                    // next weight tile: next tap, next chunk, or the first of the next tile
-                    if (tapi + 1 < ntaps) load_w(chunk, tapi + 1);
-                    else if (chunk + 1 < nchunks) load_w(chunk + 1, 0);
-                    else if (tn < ntile_total) load_w(0, 0);
-                    int aoff[MT];
+                    lds_barrier();                         // weight tile of this step (and a new window) visible
+                    const int wnext = wcur == 2 ? 0 : wcur + 1;
+                    const int wstore = wnext == 2 ? 0 : wnext + 1;
+                    store_w(wstore);                       // tile of step +2; its buffer was read during step -1
+                    load_w_next();                         // tile of step +3
+                    if constexpr (MT * NT <= 4) {
+                        if (tapi == 0) {                   // first step on a new window: nothing was prefetched
+                            a_offsets(0, aoff);
+                            load_frag(fa, aoff, wcur, 0);
+                        }
+                        const bool chain = tapi + 1 < ntaps;   // the next step reads the same window
+                        if (chain) a_offsets(tapi + 1, aoff_n);
+                        // 4 k-steps; the fragments of the next one (or of the next step's first) ride under the MFMAs
+                        __builtin_amdgcn_sched_barrier(0);
+                        load_frag(fb, aoff, wcur, 1);
+                        mma_frag(fa);
+                        CB_INTERLEAVE(MT + NT, MT * NT)
+                        __builtin_amdgcn_sched_barrier(0);
+                        load_frag(fa, aoff, wcur, 2);
+                        mma_frag(fb);
+                        CB_INTERLEAVE(MT + NT, MT * NT)
+                        __builtin_amdgcn_sched_barrier(0);
+                        load_frag(fb, aoff, wcur, 3);
+                        mma_frag(fa);
+                        CB_INTERLEAVE(MT + NT, MT * NT)
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (chain) load_frag(fa, aoff_n, wnext, 0);
+                        mma_frag(fb);
+                        CB_INTERLEAVE(MT + NT, MT * NT)
+                        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int m = 0; m < MT; ++m) {
-                        const int fr = a.fs * t_out[m] + a.foff[tapi];
-                        const bool ok = rvalid[m] && fr >= 0 && fr < Tin;
-                        aoff[m] = (ok ? ((fr - flo) * V + vj[m]) * CB_RS : ZOFF) + h * 16;
-                    }
-                    const char* wb = wbuf + (size_t)wpar * CB_BN * CB_RS + ((wc * NT) * 32 + l31) * CB_RS + h * 16;
+                        for (int m = 0; m < MT; ++m) aoff[m] = aoff_n[m];
+                    } else {
+                        // the 8-accumulator tile leaves too few registers for a second fragment set: plain k-step
+                        // loop, the compiler interleaves its 24 reads with the 32 MFMAs
+                        a_offsets(tapi, aoff);
 #pragma unroll
-                    for (int s = 0; s < 4; ++s) {
-                        i32x4 af[MT];
-#pragma unroll
-                        for (int m = 0; m < MT; ++m) af[m] = *(const i32x4*)(win + aoff[m] + s * 32);
-#pragma unroll
-                        for (int n = 0; n < NT; ++n) {
-                            const i32x4 bf = *(const i32x4*)(wb + n * 32 * CB_RS + s * 32);
-#pragma unroll
-                            for (int m = 0; m < MT; ++m) mma_step<bf16>(acc[m][n], af[m], bf);
+                        for (int s = 0; s < 4; ++s) {
+                            load_frag(fa, aoff, wcur, s);
+                            mma_frag(fa);
                         }
                     }
-                    wpar ^= 1;
+                    wcur = wnext;
                 }
             }
         }
-        __syncthreads();                                   // every wave is done with the window and weight tiles
+        lds_barrier();                                   // every wave is done with the window and weight tiles
 
         // accumulators (+bias) -> bf16 -> staging rows
 #pragma unroll
@@ -227,7 +283,7 @@ __global__ __launch_bounds__(256) void conv_big_kernel(ConvBigArgs a) {
                     const uint32_t pk = pack_bf16x2(acc[m][n][r] + biasv[n], 0.f);
                     *(uint16_t*)(smem + (size_t)rl * SRS + col * 2) = (uint16_t)(pk & 0xFFFFu);
                 }
-        __syncthreads();
+        lds_barrier();
         {
             const bool cok = co0 + eseg * 8 < Cout;
             const uint16_t* auxb = (const uint16_t*)a.aux + (size_t)b * Rreal * Cout + co0 + eseg * 8;
@@ -299,7 +355,7 @@ template <int WR, int WC, int MT, int NT, int EPI>
 static int launch_conv_big(ConvBigArgs& a, hipStream_t stream) {
     constexpr int BM = WR * MT * 32;
     a.tiles_per_sample = ceil_div_i(a.Tv * a.V, BM);
-    const size_t body = (size_t)CB_NPF * 32 * CB_RS + 2 * (size_t)CB_BN * CB_RS;
+    const size_t body = (size_t)CB_NPF * 32 * CB_RS + 3 * (size_t)CB_BN * CB_RS;
     a.zero_row = (int)((body + CB_RS - 1) / CB_RS);
     const size_t lds = (size_t)(a.zero_row + 1) * CB_RS;
     const int nct = ceil_div_i(a.Cout, CB_BN);
@@ -334,7 +390,7 @@ static int conv_big_launch_any(ConvBigArgs& a, int epi, hipStream_t stream, bool
     const bool fit256 = conv_big_win_rows(a, 256) <= CB_NPF * 32;
     const bool fit128 = conv_big_win_rows(a, 128) <= CB_NPF * 32;
     if (dry) return (fit256 || fit128) ? 0 : -1;
-    if (fit256 && (waste256 <= waste128 + 0.04 || !fit128))
+    if (fit256 && (waste256 <= waste128 + 0.10 || !fit128))
         return epi == 1 ? launch_conv_big<4, 1, 2, 4, 1>(a, stream) : launch_conv_big<4, 1, 2, 4, 0>(a, stream);
     if (fit128)
         return epi == 1 ? launch_conv_big<2, 2, 2, 2, 1>(a, stream) : launch_conv_big<2, 2, 2, 2, 0>(a, stream);

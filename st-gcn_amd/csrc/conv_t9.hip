@@ -30,6 +30,9 @@ struct ConvT9Args {
     int tiles_per_seg, segs_per_sample;
 };
 
+// scheduling pattern for a block of 8 MFMAs and 8 LDS reads: (MFMA, 2 reads) x 4, then 4 MFMAs, so the last read
+// has four MFMAs of time before its consumer
+#define INTERLEAVE_8() _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); } __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
 constexpr int T9_BM = 256;
 constexpr int T9_WR = 512;         // ring slots
 
@@ -183,49 +186,91 @@ __global__ __launch_bounds__(256) void conv_t9_kernel(ConvT9Args a) {
 
         const int prow0 = p0 + wave * 64 + l31;           // this lane's row of sub-tile m is prow0 + 32*m
         if constexpr (WRES) {
-            __syncthreads();                              // window (and, first time, weights) visible
-            for (int tap = 0; tap < ntaps; ++tap) {
+            lds_barrier();                              // window (and, first time, weights) visible
+            // fragments of one half tap (two k-steps): a0/a1 = the two row sub-tiles, b0/b1 = the two column tiles
+            struct Half { i32x4 a0[2], a1[2], b0[2], b1[2]; };
+            auto load_half = [&](Half& f, int tap, int hs) {
                 const int sh = (a.transposed ? (half - tap) : (tap - half)) * V;
-                const char* a0 = ring + (size_t)((prow0 + sh) & (T9_WR - 1)) * RS + h * 16;
-                const char* a1 = ring + (size_t)((prow0 + 32 + sh) & (T9_WR - 1)) * RS + h * 16;
-                const char* wb = wl + ((size_t)tap * 64 + l31) * WS + h * 16;
+                const char* a0 = ring + (size_t)((prow0 + sh) & (T9_WR - 1)) * RS + h * 16 + hs * 64;
+                const char* a1 = ring + (size_t)((prow0 + 32 + sh) & (T9_WR - 1)) * RS + h * 16 + hs * 64;
+                const char* wb = wl + ((size_t)tap * 64 + l31) * WS + h * 16 + hs * 64;
 #pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    const i32x4 af0 = *(const i32x4*)(a0 + s * 32);
-                    const i32x4 af1 = *(const i32x4*)(a1 + s * 32);
-                    const i32x4 bf0 = *(const i32x4*)(wb + s * 32);
-                    const i32x4 bf1 = *(const i32x4*)(wb + 32 * WS + s * 32);
-                    mma_step<bf16>(acc[0][0], af0, bf0);
-                    mma_step<bf16>(acc[0][1], af0, bf1);
-                    mma_step<bf16>(acc[1][0], af1, bf0);
-                    mma_step<bf16>(acc[1][1], af1, bf1);
+                for (int s = 0; s < 2; ++s) {
+                    f.a0[s] = *(const i32x4*)(a0 + s * 32);
+                    f.a1[s] = *(const i32x4*)(a1 + s * 32);
+                    f.b0[s] = *(const i32x4*)(wb + s * 32);
+                    f.b1[s] = *(const i32x4*)(wb + 32 * WS + s * 32);
                 }
+            };
+            auto mma_half = [&](const Half& f) {
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    mma_step<bf16>(acc[0][0], f.a0[s], f.b0[s]);
+                    mma_step<bf16>(acc[0][1], f.a0[s], f.b1[s]);
+                    mma_step<bf16>(acc[1][0], f.a1[s], f.b0[s]);
+                    mma_step<bf16>(acc[1][1], f.a1[s], f.b1[s]);
+                }
+            };
+            // software pipeline: the next half's LDS reads are in flight while this half's 8 MFMAs run
+            Half fa, fb;
+            load_half(fa, 0, 0);
+            for (int tap = 0; tap < ntaps; ++tap) {
+                // the reads of the next half ride in the shadows of this half's MFMAs
+                __builtin_amdgcn_sched_barrier(0);
+                load_half(fb, tap, 1);
+                mma_half(fa);
+                INTERLEAVE_8()
+                __builtin_amdgcn_sched_barrier(0);
+                load_half(fa, tap + 1 < ntaps ? tap + 1 : tap, 0);
+                mma_half(fb);
+                INTERLEAVE_8()
+                __builtin_amdgcn_sched_barrier(0);
             }
         } else {
             const int nsteps = NCH * ntaps;
             for (int step = 0; step < nsteps; ++step) {
                 const int chunk = step / ntaps, tap = step - chunk * ntaps;
                 store_w(step & 1);
-                __syncthreads();
+                lds_barrier();
                 if (step + 1 < nsteps) load_w(step + 1);
                 const int sh = (a.transposed ? (half - tap) : (tap - half)) * V;
                 const char* a0 = ring + (size_t)((prow0 + sh) & (T9_WR - 1)) * RS + chunk * 128 + h * 16;
                 const char* a1 = ring + (size_t)((prow0 + 32 + sh) & (T9_WR - 1)) * RS + chunk * 128 + h * 16;
                 const char* wb = wl + (size_t)(step & 1) * 64 * WS + l31 * WS + h * 16;
+                // two halves of two k-steps: the second half's reads are in flight under the first half's MFMAs
+                i32x4 fa0[2], fa1[2], fb0[2], fb1[2], ga0[2], ga1[2], gb0[2], gb1[2];
 #pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    const i32x4 af0 = *(const i32x4*)(a0 + s * 32);
-                    const i32x4 af1 = *(const i32x4*)(a1 + s * 32);
-                    const i32x4 bf0 = *(const i32x4*)(wb + s * 32);
-                    const i32x4 bf1 = *(const i32x4*)(wb + 32 * WS + s * 32);
-                    mma_step<bf16>(acc[0][0], af0, bf0);
-                    mma_step<bf16>(acc[0][1], af0, bf1);
-                    mma_step<bf16>(acc[1][0], af1, bf0);
-                    mma_step<bf16>(acc[1][1], af1, bf1);
+                for (int s = 0; s < 2; ++s) {
+                    fa0[s] = *(const i32x4*)(a0 + s * 32);
+                    fa1[s] = *(const i32x4*)(a1 + s * 32);
+                    fb0[s] = *(const i32x4*)(wb + s * 32);
+                    fb1[s] = *(const i32x4*)(wb + 32 * WS + s * 32);
+                }
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    ga0[s] = *(const i32x4*)(a0 + 64 + s * 32);
+                    ga1[s] = *(const i32x4*)(a1 + 64 + s * 32);
+                    gb0[s] = *(const i32x4*)(wb + 64 + s * 32);
+                    gb1[s] = *(const i32x4*)(wb + 32 * WS + 64 + s * 32);
+                }
+                __builtin_amdgcn_sched_barrier(0);      // keep all 16 reads ahead of the MFMAs
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    mma_step<bf16>(acc[0][0], fa0[s], fb0[s]);
+                    mma_step<bf16>(acc[0][1], fa0[s], fb1[s]);
+                    mma_step<bf16>(acc[1][0], fa1[s], fb0[s]);
+                    mma_step<bf16>(acc[1][1], fa1[s], fb1[s]);
+                }
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    mma_step<bf16>(acc[0][0], ga0[s], gb0[s]);
+                    mma_step<bf16>(acc[0][1], ga0[s], gb1[s]);
+                    mma_step<bf16>(acc[1][0], ga1[s], gb0[s]);
+                    mma_step<bf16>(acc[1][1], ga1[s], gb1[s]);
                 }
             }
         }
-        __syncthreads();                                  // every wave is done reading the window
+        lds_barrier();                                  // every wave is done reading the window
 
         // accumulators (+bias) -> bf16 -> dead ring slots (those of the rows the next tile brings in)
 #pragma unroll
@@ -239,7 +284,7 @@ __global__ __launch_bounds__(256) void conv_t9_kernel(ConvT9Args a) {
                     const uint32_t pk = pack_bf16x2(acc[m][n][r] + biasv[n], 0.f);
                     *(uint16_t*)(ring + (size_t)slot * RS + (n * 32 + l31) * 2) = (uint16_t)(pk & 0xFFFFu);
                 }
-        __syncthreads();
+        lds_barrier();
 
         // 16-byte row pieces: 256 rows x 8 pieces, 8 per thread
         {
@@ -279,7 +324,7 @@ __global__ __launch_bounds__(256) void conv_t9_kernel(ConvT9Args a) {
                 }
             }
         }
-        __syncthreads();                                  // staging slots free again
+        lds_barrier();                                  // staging slots free again
         if (more) commit_rows(pnew);
         // the __syncthreads at the top of the next tile's MFMA phase publishes the new rows
     }
@@ -309,8 +354,9 @@ static int launch_conv_t9(ConvT9Args& a, hipStream_t stream) {
     if (lds > 160 * 1024) return STGCN_ERR_ARG;
     const int ntiles = ceil_div_i(a.R, T9_BM);
     const int gy = ceil_div_i(a.Cout, 64);
-    // aim at ~2 workgroups per CU in total, but keep walks long enough to amortise the window fill
-    int segs = (512 + a.B * gy - 1) / (a.B * gy);
+    // one workgroup per CU is resident (LDS): aim at one round of 256 workgroups, so the per-workgroup start-up
+    // (weight load, first window) is paid once per CU
+    int segs = (256 + a.B * gy - 1) / (a.B * gy);
     if (segs < 1) segs = 1;
     if (segs > ntiles) segs = ntiles;
     int tps = ceil_div_i(ntiles, segs);

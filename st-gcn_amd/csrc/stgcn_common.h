@@ -113,6 +113,11 @@ __device__ __forceinline__ bool drop_keep(uint64_t idx, uint32_t seed, uint32_t 
     return x >= thr;
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains every outstanding global load and
+// store of the wave (s_waitcnt vmcnt(0)), which serialises register prefetches and epilogue stores against the
+// barrier; kernels whose waves exchange data through LDS alone use this instead.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 __device__ __forceinline__ i32x4 zero16() { i32x4 z = {0, 0, 0, 0}; return z; }
 
 static inline int ceil_div_i(int a, int b) { return (a + b - 1) / b; }

@@ -73,8 +73,11 @@ def main():
     ap.add_argument("cases", nargs="+")
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--lib", default=None, help="alternative build of libstgcn_hip.so (A/B timing on one device)")
     a = ap.parse_args()
     dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    if a.lib:
+        L._LIB_PATH = os.path.abspath(a.lib)
     L.load()
     for case in a.cases:
         fn = make(case, dtype)

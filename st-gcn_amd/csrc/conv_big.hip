@@ -10,14 +10,15 @@
 //                              of matching parity: foff = (p + pad - k) / 2.  No MFMA is spent on the zeros a
 //                              strided transposed convolution is full of; a parity without taps writes zeros.
 //
-//   - A workgroup (4 waves) owns one 128-channel tile of Cout and walks (sample, row-tile) pairs; a row tile is
+//   - A workgroup (8 or 4 waves) owns one 128-channel tile of Cout and walks (sample, row-tile) pairs; a row tile is
 //     BM = 256 (or 128) virtual output rows.  Per 64-channel chunk of Cin the window of input rows all taps need is
 //     staged once in LDS (BatchNorm+ReLU prologue applied once per element); taps read their A fragments from it at
 //     per-lane row offsets (a zero row stands in for frames outside the sample).
 //   - The NEXT window (next chunk, or the first chunk of the next tile) is fetched into registers while the current
 //     chunk's taps run, so global latency hides under 9 x 16 (or 32) MFMAs per wave; weight tiles (128 x 64 per
 //     tap) are double-buffered the same way.
-//   - Per wave 64 rows x 128 channels (BM = 256: 6 LDS fragment reads per 8 MFMAs) or 64 x 64 (BM = 128).
+//   - Per wave 64 rows x 64 channels (2 x 2 accumulator tiles); BM = 256 runs 8 waves (two per SIMD, so one wave's
+//     LDS and barrier waits hide under the other's MFMAs), BM = 128 runs 4.
 //   - Epilogue: accumulators (+bias) are rounded to bf16 into LDS, then leave as 16-byte row pieces: coalesced
 //     stores, coalesced loads of the auxiliary tensor of the fused ReLU/BatchNorm backward, per-thread statistics
 //     (fixed channels) that reach memory as one double atomic per channel per workgroup.
@@ -39,17 +40,24 @@ struct ConvBigArgs {
 // scheduling pattern for one k-step: NR LDS reads paired two-by-two behind the first MFMAs, then the remaining MFMAs
 #define CB_INTERLEAVE(NR, NM) _Pragma("unroll") for (int i_ = 0; i_ < (NR) / 2; ++i_) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); } __builtin_amdgcn_sched_group_barrier(0x008, (NM) - (NR) / 2, 0);
 constexpr int CB_RS = 144;
-constexpr int CB_NPF = 17;          // window pieces per thread: up to 544 window rows
+constexpr int CB_WIN_ROWS = 544;    // window capacity in rows
 constexpr int CB_BN = 128;
 
 template <int WR, int WC, int MT, int NT, int EPI>
-__global__ __launch_bounds__(256) void conv_big_kernel(ConvBigArgs a) {
+__global__ __launch_bounds__(WR * WC * 64) void conv_big_kernel(ConvBigArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int BM = WR * MT * 32;
+    constexpr int NTH = WR * WC * 64;                    // threads per workgroup (256 or 512)
+    constexpr int RPP = NTH / 8;                         // window rows staged per pass
+    constexpr int NPF = (CB_WIN_ROWS + RPP - 1) / RPP;   // window pieces per thread
+    constexpr int WPT = CB_BN * 8 / NTH;                 // weight-tile pieces per thread
+    constexpr int ERP = NTH / 16;                        // epilogue rows per pass
+    constexpr int EPP = BM / ERP;                        // epilogue passes per tile
+    constexpr int EG = EPP < 8 ? EPP : 8;                // passes whose auxiliary loads are issued together
     static_assert(WC * NT * 32 == CB_BN, "column tile is 128");
     constexpr int SRS = CB_BN * 2 + 16;                  // epilogue staging row stride
     char* win = smem;
-    char* wbuf = smem + (size_t)CB_NPF * 32 * CB_RS;     // 3 x [128][RS]
+    char* wbuf = smem + (size_t)CB_WIN_ROWS * CB_RS;     // 3 x [128][RS]
     const int ZOFF = a.zero_row * CB_RS;                 // byte offset of the all-zero row
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -63,8 +71,8 @@ __global__ __launch_bounds__(256) void conv_big_kernel(ConvBigArgs a) {
 
     if (tid < CB_RS / 16) *(i32x4*)(smem + ZOFF + tid * 16) = zero16();
 
-    const int sseg = tid & 7, srow = tid >> 3;           // window staging: 32 rows per pass
-    const int eseg = tid & 15, erow = tid >> 4;          // epilogue: 16 rows per pass, fixed 8 channels
+    const int sseg = tid & 7, srow = tid >> 3;           // window staging: RPP rows per pass
+    const int eseg = tid & 15, erow = tid >> 4;          // epilogue: ERP rows per pass, fixed 8 channels
     const bool has_pro = a.pro_scale != nullptr;
 
     float e_sc[8], e_sh[8], e_mu[8], e_rs[8], s1[8], s2[8];
@@ -95,12 +103,12 @@ __global__ __launch_bounds__(256) void conv_big_kernel(ConvBigArgs a) {
         flo = f0;
         wrows = max(0, (f1 - f0 + 1) * V);
     };
-    i32x4 pf[CB_NPF];
+    i32x4 pf[NPF];
     auto fetch_win = [&](int b, int flo, int wrows, int chunk) {
         const char* base = (const char*)a.in + (((size_t)b * Tin + flo) * V * (size_t)Cin + (size_t)chunk * 64 + sseg * 8) * 2;
 #pragma unroll
-        for (int i = 0; i < CB_NPF; ++i) {
-            const int row = srow + 32 * i;
+        for (int i = 0; i < NPF; ++i) {
+            const int row = srow + RPP * i;
             if (row < wrows) pf[i] = *(const i32x4*)(base + (size_t)row * Cin * 2);
         }
     };
@@ -111,8 +119,8 @@ __global__ __launch_bounds__(256) void conv_big_kernel(ConvBigArgs a) {
             for (int j = 0; j < 8; ++j) { psc[j] = a.pro_scale[chunk * 64 + sseg * 8 + j]; psh[j] = a.pro_shift[chunk * 64 + sseg * 8 + j]; }
         }
 #pragma unroll
-        for (int i = 0; i < CB_NPF; ++i) {
-            const int row = srow + 32 * i;
+        for (int i = 0; i < NPF; ++i) {
+            const int row = srow + RPP * i;
             if (row < wrows) {
                 i32x4 v = pf[i];
                 if (has_pro) {
@@ -126,12 +134,12 @@ __global__ __launch_bounds__(256) void conv_big_kernel(ConvBigArgs a) {
             }
         }
     };
-    i32x4 wreg[4];
+    i32x4 wreg[WPT];
     auto load_w = [&](int chunk, int tapi) {
         const int tap = a.wk[tapi];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int p = tid + 256 * i;
+        for (int i = 0; i < WPT; ++i) {
+            const int p = tid + NTH * i;
             const int n = p >> 3, sg = p & 7;
             const int co = co0 + n;
             wreg[i] = zero16();
@@ -140,8 +148,8 @@ __global__ __launch_bounds__(256) void conv_big_kernel(ConvBigArgs a) {
     };
     auto store_w = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int p = tid + 256 * i;
+        for (int i = 0; i < WPT; ++i) {
+            const int p = tid + NTH * i;
             *(i32x4*)(wbuf + (size_t)buf * CB_BN * CB_RS + (p >> 3) * CB_RS + (p & 7) * 16) = wreg[i];
         }
     };
@@ -228,7 +236,7 @@ __global__ __launch_bounds__(256) void conv_big_kernel(ConvBigArgs a) {
                     const int wstore = wnext == 2 ? 0 : wnext + 1;
                     store_w(wstore);                       // tile of step +2; its buffer was read during step -1
                     load_w_next();                         // tile of step +3
-                    if constexpr (MT * NT <= 4) {
+                    if constexpr (true) {
                         if (tapi == 0) {                   // first step on a new window: nothing was prefetched
                             a_offsets(0, aoff);
                             load_frag(fa, aoff, wcur, 0);
@@ -289,12 +297,12 @@ __global__ __launch_bounds__(256) void conv_big_kernel(ConvBigArgs a) {
             const uint16_t* auxb = (const uint16_t*)a.aux + (size_t)b * Rreal * Cout + co0 + eseg * 8;
             uint16_t* outb = (uint16_t*)a.out + (size_t)b * Rreal * Cout + co0 + eseg * 8;
 #pragma unroll 1
-            for (int g = 0; g < BM / 128; ++g) {
-                int rrow[8];
-                i32x4 av[8];
+            for (int g = 0; g < EPP / EG; ++g) {
+                int rrow[EG];
+                i32x4 av[EG];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const int u = r0 + erow + 16 * (g * 8 + i);
+                for (int i = 0; i < EG; ++i) {
+                    const int u = r0 + erow + ERP * (g * EG + i);
                     int rr = -1;
                     if (u < r1 && cok) {
                         if (a.os == 1) rr = u;
@@ -307,9 +315,9 @@ __global__ __launch_bounds__(256) void conv_big_kernel(ConvBigArgs a) {
                     }
                 }
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
+                for (int i = 0; i < EG; ++i) {
                     if (rrow[i] >= 0) {
-                        const int rl = erow + 16 * (g * 8 + i);
+                        const int rl = erow + ERP * (g * EG + i);
                         i32x4 v = *(const i32x4*)(smem + (size_t)rl * SRS + eseg * 16);
                         float f[8];
                         unpack16<bf16>(v, f);
@@ -337,15 +345,15 @@ __global__ __launch_bounds__(256) void conv_big_kernel(ConvBigArgs a) {
 
     if (a.stats) {
         __syncthreads();
-        float* red = (float*)smem;                        // [256][16]
+        float* red = (float*)smem;                        // [NTH][16]
 #pragma unroll
         for (int j = 0; j < 8; ++j) { red[tid * 16 + j] = s1[j]; red[tid * 16 + 8 + j] = s2[j]; }
         __syncthreads();
-        {
+        if (tid < 256) {
             const int which = tid >> 7, c = tid & 127;    // which: 0 = s1, 1 = s2 ; c = channel within the tile
             const int sg = c >> 3, j = c & 7;
             float t = 0.f;
-            for (int r = 0; r < 16; ++r) t += red[(r * 16 + sg) * 16 + which * 8 + j];
+            for (int r = 0; r < ERP; ++r) t += red[(r * 16 + sg) * 16 + which * 8 + j];
             if (co0 + c < Cout) atomicAdd(&a.stats[which * Cout + co0 + c], (double)t);
         }
     }
@@ -355,7 +363,7 @@ template <int WR, int WC, int MT, int NT, int EPI>
 static int launch_conv_big(ConvBigArgs& a, hipStream_t stream) {
     constexpr int BM = WR * MT * 32;
     a.tiles_per_sample = ceil_div_i(a.Tv * a.V, BM);
-    const size_t body = (size_t)CB_NPF * 32 * CB_RS + 3 * (size_t)CB_BN * CB_RS;
+    const size_t body = (size_t)CB_WIN_ROWS * CB_RS + 3 * (size_t)CB_BN * CB_RS;
     a.zero_row = (int)((body + CB_RS - 1) / CB_RS);
     const size_t lds = (size_t)(a.zero_row + 1) * CB_RS;
     const int nct = ceil_div_i(a.Cout, CB_BN);
@@ -364,7 +372,7 @@ static int launch_conv_big(ConvBigArgs& a, hipStream_t stream) {
     auto kern = conv_big_kernel<WR, WC, MT, NT, EPI>;
     static bool set = false;
     if (!set) { if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return STGCN_ERR_LAUNCH; set = true; }
-    hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)nct), dim3(256), lds, stream, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)nct), dim3(WR * WC * 64), lds, stream, a);
     return hipGetLastError() == hipSuccess ? STGCN_OK : STGCN_ERR_LAUNCH;
 }
 
@@ -387,13 +395,13 @@ static int conv_big_launch_any(ConvBigArgs& a, int epi, hipStream_t stream, bool
     // 256-row tiles read fewer fragments per MFMA; 128-row tiles waste less on the ragged last tile of a sample
     const double waste256 = 1.0 - (double)Rv / (ceil_div_i(Rv, 256) * 256.0);
     const double waste128 = 1.0 - (double)Rv / (ceil_div_i(Rv, 128) * 128.0);
-    const bool fit256 = conv_big_win_rows(a, 256) <= CB_NPF * 32;
-    const bool fit128 = conv_big_win_rows(a, 128) <= CB_NPF * 32;
+    const bool fit256 = conv_big_win_rows(a, 256) <= CB_WIN_ROWS;
+    const bool fit128 = conv_big_win_rows(a, 128) <= CB_WIN_ROWS;
     if (dry) return (fit256 || fit128) ? 0 : -1;
     if (fit256 && (waste256 <= waste128 + 0.10 || !fit128))
-        return epi == 1 ? launch_conv_big<4, 1, 2, 4, 1>(a, stream) : launch_conv_big<4, 1, 2, 4, 0>(a, stream);
+        return epi == 1 ? launch_conv_big<4, 2, 2, 2, 1>(a, stream) : launch_conv_big<4, 2, 2, 2, 0>(a, stream);
     if (fit128)
-        return epi == 1 ? launch_conv_big<2, 2, 2, 2, 1>(a, stream) : launch_conv_big<2, 2, 2, 2, 0>(a, stream);
+        return epi == 1 ? launch_conv_big<4, 2, 1, 2, 1>(a, stream) : launch_conv_big<4, 2, 1, 2, 0>(a, stream);
     return -1;
 }
 

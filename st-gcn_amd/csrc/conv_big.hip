@@ -41,7 +41,7 @@ struct ConvBigArgs {
 #define CB_INTERLEAVE(NR, NM) _Pragma("unroll") for (int i_ = 0; i_ < (NR) / 2; ++i_) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); } __builtin_amdgcn_sched_group_barrier(0x008, (NM) - (NR) / 2, 0);
 constexpr int CB_RS = 144;
 constexpr int CB_WIN_ROWS = 544;    // window capacity in rows
-constexpr int CB_BN = 128;
+constexpr int CB_BN_MAX = 128;      // widest column tile (sizes the weight buffers)
 
 template <int WR, int WC, int MT, int NT, int EPI>
 __global__ __launch_bounds__(WR * WC * 64) void conv_big_kernel(ConvBigArgs a) {
@@ -50,12 +50,14 @@ __global__ __launch_bounds__(WR * WC * 64) void conv_big_kernel(ConvBigArgs a) {
     constexpr int NTH = WR * WC * 64;                    // threads per workgroup (256 or 512)
     constexpr int RPP = NTH / 8;                         // window rows staged per pass
     constexpr int NPF = (CB_WIN_ROWS + RPP - 1) / RPP;   // window pieces per thread
-    constexpr int WPT = CB_BN * 8 / NTH;                 // weight-tile pieces per thread
-    constexpr int ERP = NTH / 16;                        // epilogue rows per pass
+    constexpr int BN = WC * NT * 32;                     // column tile: 128 or 64 output channels
+    constexpr int EPR = BN / 8;                          // 16-byte pieces per output row of the tile
+    constexpr int WPT = BN * 8 / NTH;                    // weight-tile pieces per thread
+    constexpr int ERP = NTH / EPR;                       // epilogue rows per pass
     constexpr int EPP = BM / ERP;                        // epilogue passes per tile
     constexpr int EG = EPP < 8 ? EPP : 8;                // passes whose auxiliary loads are issued together
-    static_assert(WC * NT * 32 == CB_BN, "column tile is 128");
-    constexpr int SRS = CB_BN * 2 + 16;                  // epilogue staging row stride
+    static_assert(BN == 128 || BN == 64, "column tile is 128 or 64");
+    constexpr int SRS = BN * 2 + 16;                  // epilogue staging row stride
     char* win = smem;
     char* wbuf = smem + (size_t)CB_WIN_ROWS * CB_RS;     // 3 x [128][RS]
     const int ZOFF = a.zero_row * CB_RS;                 // byte offset of the all-zero row
@@ -64,7 +66,7 @@ __global__ __launch_bounds__(WR * WC * 64) void conv_big_kernel(ConvBigArgs a) {
     const int l31 = lane & 31, h = lane >> 5;
     const int wr = wave % WR, wc = wave / WR;
     const int V = a.V, Cin = a.Cin, Cout = a.Cout, Tin = a.Tin, ntaps = a.ntaps;
-    const int co0 = blockIdx.y * CB_BN;
+    const int co0 = blockIdx.y * BN;
     const int Rv = a.Tv * V, Rreal = a.Tout_real * V;
     const int nchunks = Cin / 64;
     const int ntile_total = a.B * a.tiles_per_sample;
@@ -72,7 +74,7 @@ __global__ __launch_bounds__(WR * WC * 64) void conv_big_kernel(ConvBigArgs a) {
     if (tid < CB_RS / 16) *(i32x4*)(smem + ZOFF + tid * 16) = zero16();
 
     const int sseg = tid & 7, srow = tid >> 3;           // window staging: RPP rows per pass
-    const int eseg = tid & 15, erow = tid >> 4;          // epilogue: ERP rows per pass, fixed 8 channels
+    const int eseg = tid % EPR, erow = tid / EPR;          // epilogue: ERP rows per pass, fixed 8 channels
     const bool has_pro = a.pro_scale != nullptr;
 
     float e_sc[8], e_sh[8], e_mu[8], e_rs[8], s1[8], s2[8];
@@ -150,7 +152,7 @@ __global__ __launch_bounds__(WR * WC * 64) void conv_big_kernel(ConvBigArgs a) {
 #pragma unroll
         for (int i = 0; i < WPT; ++i) {
             const int p = tid + NTH * i;
-            *(i32x4*)(wbuf + (size_t)buf * CB_BN * CB_RS + (p >> 3) * CB_RS + (p & 7) * 16) = wreg[i];
+            *(i32x4*)(wbuf + (size_t)buf * BN * CB_RS + (p >> 3) * CB_RS + (p & 7) * 16) = wreg[i];
         }
     };
 
@@ -211,7 +213,7 @@ __global__ __launch_bounds__(WR * WC * 64) void conv_big_kernel(ConvBigArgs a) {
                 }
             };
             auto load_frag = [&](Frag& f, const int (&aoff)[MT], int wbi, int s) {
-                const char* wb = wbuf + (size_t)wbi * CB_BN * CB_RS + ((wc * NT) * 32 + l31) * CB_RS + h * 16;
+                const char* wb = wbuf + (size_t)wbi * BN * CB_RS + ((wc * NT) * 32 + l31) * CB_RS + h * 16;
 #pragma unroll
                 for (int m = 0; m < MT; ++m) f.af[m] = *(const i32x4*)(win + aoff[m] + s * 32);
 #pragma unroll
@@ -349,11 +351,11 @@ __global__ __launch_bounds__(WR * WC * 64) void conv_big_kernel(ConvBigArgs a) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) { red[tid * 16 + j] = s1[j]; red[tid * 16 + 8 + j] = s2[j]; }
         __syncthreads();
-        if (tid < 256) {
-            const int which = tid >> 7, c = tid & 127;    // which: 0 = s1, 1 = s2 ; c = channel within the tile
+        if (tid < 2 * BN) {
+            const int which = tid / BN, c = tid % BN;     // which: 0 = s1, 1 = s2 ; c = channel within the tile
             const int sg = c >> 3, j = c & 7;
             float t = 0.f;
-            for (int r = 0; r < ERP; ++r) t += red[(r * 16 + sg) * 16 + which * 8 + j];
+            for (int r = 0; r < ERP; ++r) t += red[(r * EPR + sg) * 16 + which * 8 + j];
             if (co0 + c < Cout) atomicAdd(&a.stats[which * Cout + co0 + c], (double)t);
         }
     }
@@ -363,10 +365,11 @@ template <int WR, int WC, int MT, int NT, int EPI>
 static int launch_conv_big(ConvBigArgs& a, hipStream_t stream) {
     constexpr int BM = WR * MT * 32;
     a.tiles_per_sample = ceil_div_i(a.Tv * a.V, BM);
-    const size_t body = (size_t)CB_WIN_ROWS * CB_RS + 3 * (size_t)CB_BN * CB_RS;
+    constexpr int BN = WC * NT * 32;
+    const size_t body = (size_t)CB_WIN_ROWS * CB_RS + 3 * (size_t)CB_BN_MAX * CB_RS;
     a.zero_row = (int)((body + CB_RS - 1) / CB_RS);
     const size_t lds = (size_t)(a.zero_row + 1) * CB_RS;
-    const int nct = ceil_div_i(a.Cout, CB_BN);
+    const int nct = ceil_div_i(a.Cout, BN);
     int gx = max(1, 256 / nct);
     if (gx > a.B * a.tiles_per_sample) gx = a.B * a.tiles_per_sample;
     auto kern = conv_big_kernel<WR, WC, MT, NT, EPI>;
@@ -398,10 +401,15 @@ static int conv_big_launch_any(ConvBigArgs& a, int epi, hipStream_t stream, bool
     const bool fit256 = conv_big_win_rows(a, 256) <= CB_WIN_ROWS;
     const bool fit128 = conv_big_win_rows(a, 128) <= CB_WIN_ROWS;
     if (dry) return (fit256 || fit128) ? 0 : -1;
-    if (fit256 && (waste256 <= waste128 + 0.10 || !fit128))
+    const bool narrow = a.Cout <= 64;                      // 64-channel column tile: 8 waves of 32 rows x 64 channels
+    if (fit256 && (waste256 <= waste128 + 0.10 || !fit128)) {
+        if (narrow) return epi == 1 ? launch_conv_big<8, 1, 1, 2, 1>(a, stream) : launch_conv_big<8, 1, 1, 2, 0>(a, stream);
         return epi == 1 ? launch_conv_big<4, 2, 2, 2, 1>(a, stream) : launch_conv_big<4, 2, 2, 2, 0>(a, stream);
-    if (fit128)
+    }
+    if (fit128) {
+        if (narrow) return epi == 1 ? launch_conv_big<4, 1, 1, 2, 1>(a, stream) : launch_conv_big<4, 1, 1, 2, 0>(a, stream);
         return epi == 1 ? launch_conv_big<4, 2, 1, 2, 1>(a, stream) : launch_conv_big<4, 2, 1, 2, 0>(a, stream);
+    }
     return -1;
 }
 

@@ -187,8 +187,9 @@ __global__ void conv_wgrad_reduce_kernel(const float* slab, float* dW, int npart
 
 // ------------------------------------------------------------------------------------------
 // bf16 fast path for "same"-padded temporal kernels with stride 1 or 2: persistent workgroups with an LDS ring,
-// as in conv_t9.  A workgroup owns one (64 co x 64 ci) tile pair for all taps (each wave a 32x32 quadrant,
-// 9 accumulators) and walks runs of consecutive output-row tiles of one sample.  Input rows (64-channel slice,
+// as in conv_t9.  A workgroup owns one (64 co x 64 ci) tile pair for all taps and walks runs of consecutive
+// output-row tiles of one sample.  Its 8 waves (two per SIMD) are 4 quadrants (32 x 32, 9 accumulators each) x 2
+// k-step parities; the two parities are summed through LDS at the end.  Input rows (64-channel slice,
 // prologue applied, zeros outside the sample) sit in a 512-slot ring (slot = row & 511) so each is fetched once
 // per run; dout tiles are double-buffered.  The next tile's rows are fetched into registers under the MFMA phase.
 //   stride 1: 256 output rows per tile (16 k-steps), input advances 256 rows per tile.
@@ -203,12 +204,13 @@ struct ConvWgradRingArgs {
 };
 
 template <int STRIDE>
-__global__ __launch_bounds__(256) void conv_wgrad_ring_kernel(ConvWgradRingArgs a) {
+__global__ __launch_bounds__(512) void conv_wgrad_ring_kernel(ConvWgradRingArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int RS = 144;
     constexpr int KS = STRIDE == 1 ? 16 : 8;              // k-steps (16 output rows each) per tile
     constexpr int DROWS = KS * 16;                        // dout rows per tile buffer
-    constexpr int DPASS = DROWS / 32;                     // staging passes for a dout tile
+    constexpr int DPASS = DROWS / 64;                     // staging passes for a dout tile (64 rows per pass)
+    constexpr int KW = KS / 2;                            // k-steps per wave: waves 0-3 take the even ones, 4-7 the odd
     char* ring = smem;                                   // [512][RS]
     char* dt = smem + 512 * RS;                          // 2 x [DROWS][RS]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -216,7 +218,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_ring_kernel(ConvWgradRingArgs 
     const int V = a.V, Rin = a.Rin, Rout = a.Rout, Cin = a.Cin, Cout = a.Cout, ntaps = a.ntaps;
     const int half = (ntaps - 1) / 2;
     const int co0 = blockIdx.y * 64, ci0 = blockIdx.z * 64;
-    const int coh = wave & 1, cih = wave >> 1;
+    const int coh = wave & 1, cih = (wave >> 1) & 1, kg = wave >> 2;
     const int q4 = (lane & 15) >> 2, p4 = lane & 3, g1 = (lane >> 4) & 1;
     const int acol = (coh * 32 + 16 * g1 + 4 * p4) * 2;
     const int bcol = (cih * 32 + 16 * g1 + 4 * p4) * 2;
@@ -224,18 +226,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_ring_kernel(ConvWgradRingArgs 
     const int in_adv = STRIDE * tile_rows;                // input rows one tile advances by
     const int span = STRIDE == 1 ? 256 + 2 * half * V : in_adv + (2 * half - 1) * V;   // input rows one tile touches
 
-    // stride 2: input-row offset of this lane's two address rows in every k-step (rows past the tile pair with
-    // zero dout rows; they are pointed at row 0 of the span, which always holds finite data)
-    int roff[STRIDE == 1 ? 1 : KS][2];
-    if constexpr (STRIDE != 1) {
-#pragma unroll
-        for (int s = 0; s < KS; ++s)
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int j = 16 * s + 8 * h + q4 + 4 * u;
-                roff[s][u] = j < tile_rows ? j + (j / V) * V : 0;
-            }
-    }
+    // input-row offset (from the span start) that pairs with output row j of the tile.  Stride 2: j + (j / V) * V;
+    // rows past the tile pair with zero dout rows and are pointed at row 0 of the span, which always holds finite
+    // data.  j < 256 and V <= 32, so the float quotient is exact.
+    const float rV = 1.0f / (float)V;
+    auto in_off = [&](int j) -> int {
+        if constexpr (STRIDE == 1) return j;
+        if (j >= tile_rows) return 0;
+        const int q = (int)(((float)j + 0.5f) * rV);
+        return j + q * V;
+    };
 
     f32x16 acc[9];
 #pragma unroll
@@ -243,7 +243,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_ring_kernel(ConvWgradRingArgs 
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-    const int sseg = tid & 7, srow = tid >> 3;           // staging: 32 rows per pass
+    const int sseg = tid & 7, srow = tid >> 3;           // staging: 64 rows per pass
     float psc[8], psh[8];
     const bool has_pro = a.pro_scale != nullptr;
 #pragma unroll
@@ -269,19 +269,19 @@ __global__ __launch_bounds__(256) void conv_wgrad_ring_kernel(ConvWgradRingArgs 
         if (tile_beg >= tile_end) continue;
         const uint16_t* inb = (const uint16_t*)a.in + (size_t)b * Rin * Cin + ci0;
         const uint16_t* dob = (const uint16_t*)a.dout + (size_t)b * Rout * Cout + co0;
-        i32x4 pf[8];
+        i32x4 pf[4];
         auto fetch_in = [&](int p_first) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int p = p_first + srow + 32 * i;
+            for (int i = 0; i < 4; ++i) {
+                const int p = p_first + srow + 64 * i;
                 pf[i] = zero16();
                 if (p >= 0 && p < Rin) pf[i] = *(const i32x4*)(inb + (size_t)p * Cin + sseg * 8);
             }
         };
         auto commit_in = [&](int p_first, int nrows) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int rel = srow + 32 * i;
+            for (int i = 0; i < 4; ++i) {
+                const int rel = srow + 64 * i;
                 const int p = p_first + rel;
                 if (rel < nrows) {
                     i32x4 v = pf[i];
@@ -293,7 +293,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_ring_kernel(ConvWgradRingArgs 
         auto fetch_do = [&](int p_first) {
 #pragma unroll
             for (int i = 0; i < DPASS; ++i) {
-                const int rel = srow + 32 * i;
+                const int rel = srow + 64 * i;
                 const int p = p_first + rel;
                 pf[i] = zero16();
                 if (rel < tile_rows && p < Rout && co_ok) pf[i] = *(const i32x4*)(dob + (size_t)p * Cout + sseg * 8);
@@ -302,11 +302,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_ring_kernel(ConvWgradRingArgs 
         auto commit_do = [&](int buf) {
 #pragma unroll
             for (int i = 0; i < DPASS; ++i)
-                *(i32x4*)(dt + (size_t)buf * DROWS * RS + (srow + 32 * i) * RS + sseg * 16) = pf[i];
+                *(i32x4*)(dt + (size_t)buf * DROWS * RS + (srow + 64 * i) * RS + sseg * 16) = pf[i];
         };
 
         int p0 = tile_beg * tile_rows;                    // first output row of the tile
-        __syncthreads();                                  // previous run fully consumed
+        lds_barrier();                                  // previous run fully consumed
         {
             const int first = STRIDE * p0 - half * V;
             for (int base = 0; base < span; base += 256) {
@@ -321,7 +321,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_ring_kernel(ConvWgradRingArgs 
             const bool more = tile + 1 < tile_end;
             const int first = STRIDE * p0 - half * V;     // first input row of this tile's span
             const int pnew = first + span;                // first input row the next tile adds
-            __syncthreads();                              // ring and dt[cur] visible
+            lds_barrier();                              // ring and dt[cur] visible
             if (more) fetch_do(p0 + tile_rows);
             const char* dcur = dt + (size_t)cur * DROWS * RS;
             auto kstep = [&](int s, int ro0, int ro1) {
@@ -340,36 +340,43 @@ __global__ __launch_bounds__(256) void conv_wgrad_ring_kernel(ConvWgradRingArgs 
                     }
                 }
             };
-            if constexpr (STRIDE == 1) {
 #pragma unroll 1
-                for (int hs = 0; hs < 2; ++hs) {
+            for (int hs = 0; hs < 2; ++hs) {
 #pragma unroll 2
-                    for (int s8 = 0; s8 < 8; ++s8) {
-                        const int s = hs * 8 + s8;
-                        const int j = 16 * s + 8 * h + q4;
-                        kstep(s, j, j + 4);
-                    }
-                    if (hs == 0 && more) {
-                        commit_do(cur ^ 1);               // last read a tile ago: every wave has passed a barrier since
-                        fetch_in(pnew);
-                    }
+                for (int sj = 0; sj < KW / 2; ++sj) {
+                    const int s = 2 * (hs * (KW / 2) + sj) + kg;
+                    const int j = 16 * s + 8 * h + q4;
+                    kstep(s, in_off(j), in_off(j + 4));
                 }
-            } else {
-#pragma unroll
-                for (int s = 0; s < KS / 2; ++s) kstep(s, roff[s][0], roff[s][1]);
-                if (more) {
-                    commit_do(cur ^ 1);
+                if (hs == 0 && more) {
+                    commit_do(cur ^ 1);                   // last read a tile ago: every wave has passed a barrier since
                     fetch_in(pnew);
                 }
-#pragma unroll
-                for (int s = KS / 2; s < KS; ++s) kstep(s, roff[s][0], roff[s][1]);
             }
-            __syncthreads();                              // every wave is done reading the ring
+            lds_barrier();                              // every wave is done reading the ring
             if (more) commit_in(pnew, 256);
             cur ^= 1;
         }
     }
 
+    // fold the odd-k-step waves into their even partners through LDS, one tap at a time
+    float* red = (float*)smem;                            // [4][16][64] floats
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        if (t < ntaps) {
+            lds_barrier();
+            if (kg == 1) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) red[((wave & 3) * 16 + r) * 64 + lane] = acc[t][r];
+            }
+            lds_barrier();
+            if (kg == 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][r] += red[(wave * 16 + r) * 64 + lane];
+            }
+        }
+    }
+    if (kg != 0) return;
     const int part = blockIdx.x;
     const int cob = co0 + coh * 32;
     const int ci = ci0 + cih * 32 + l31;
@@ -417,8 +424,8 @@ static int conv_wgrad_ring_try(const void* in, const void* dout, float* dW, cons
     static bool set[2] = {false, false};
     if (!set[stride - 1]) { if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return STGCN_ERR_LAUNCH; set[stride - 1] = true; }
     const dim3 grid((unsigned)nwg, (unsigned)ncot, (unsigned)ncit);
-    if (stride == 1) hipLaunchKernelGGL(conv_wgrad_ring_kernel<1>, grid, dim3(256), lds, stream, a);
-    else hipLaunchKernelGGL(conv_wgrad_ring_kernel<2>, grid, dim3(256), lds, stream, a);
+    if (stride == 1) hipLaunchKernelGGL(conv_wgrad_ring_kernel<1>, grid, dim3(512), lds, stream, a);
+    else hipLaunchKernelGGL(conv_wgrad_ring_kernel<2>, grid, dim3(512), lds, stream, a);
     if (hipGetLastError() != hipSuccess) return STGCN_ERR_LAUNCH;
     const size_t n = (size_t)ntaps * Cout * Cin;
     const int left = fold_parts(a.slab, nwg, n, stream);

@@ -56,11 +56,12 @@ int stgcn_conv_wgrad(int dtype, const void* in, const void* dout, float* dW,
 
 /* Fused graph convolution over NF = B*T frames:
  *   out[f,a,n] = sum_k sum_b adj[k][a][b] * (sum_c in[f,b,c]*w[k][n][c] + bias[k][n])  (+ add[f,a,n])
- * Forward:  adj[k][w][v] = (A*importance)[k][v][w], w[k][co][ci] = conv.weight[k*Cout+co][ci].
- * Backward: adj[k][v][w] = (A*importance)[k][v][w], w[k][ci][co] = conv.weight[k*Cout+co][ci], no bias.
+ * adj_transposed != 0 reads adj[k][b][a] in place of adj[k][a][b], so both directions take A*importance as stored:
+ * Forward:  adj = A*importance, adj_transposed = 1, w[k][co][ci] = conv.weight[k*Cout+co][ci].
+ * Backward: adj = A*importance, adj_transposed = 0, w[k][ci][co] = conv.weight[k*Cout+co][ci], no bias.
  * Replaces: ConvTemporalGraphical.forward -- nn.Conv2d 1x1 (net/utils/tgcn.py:60), view (tgcn.py:62-63) and
  * torch.einsum('nkctv,kvw->nctw') (tgcn.py:64) -- and its input gradient; the K*C intermediate stays in registers. */
-int stgcn_gcn_fused(int dtype, const void* in, const void* w_packed, const float* adj, const float* bias,
+int stgcn_gcn_fused(int dtype, const void* in, const void* w_packed, const float* adj, int adj_transposed, const float* bias,
                     void* out, const void* add, double* stats,
                     int NF, int V, int Cin, int Nout, int K, void* stream);
 
@@ -126,6 +127,14 @@ int stgcn_head_fc_fwd(const float* pooled, const float* W, const float* bias, fl
                       int N, int M, int C, int ncls, void* stream);
 int stgcn_head_fc_bwd(const float* dlogits, const float* pooled, const float* W, float* dW, float* db, float* dpm,
                       int N, int M, int C, int ncls, void* stream);
+
+/* Re-packs every convolution weight of a model in one launch.  table: ndesc descriptors in device memory, each
+ * 10 x 8 bytes { const float* src; void* w; void* wt; int64 G, Cout, Cin, Cinp, sg, sco, sci }: element (g, co, ci) =
+ * src[g*sg + co*sco + ci*sci] is written in the compute dtype to w[g][co][cip] and wt[g][cip][co] (cip < Cinp,
+ * zero past Cin; either destination may be null).  max_elems = the largest G*Cout*Cinp.
+ * Replaces: the weight reads inside nn.Conv2d at net/utils/tgcn.py:60 and net/st_gcn.py:162-168, 181-185 (the
+ * kernels above want the weights tap- / partition-major in the activation dtype). */
+int stgcn_pack_weights(int dtype, const void* table, int ndesc, size_t max_elems, void* stream);
 
 /* SGD with momentum / Nesterov / weight decay over flat float32 buffers; g is multiplied by grad_scale first.
  * Replaces: optim.SGD(...).step() as configured at processor/recognition.py:46-53. */

@@ -617,6 +617,42 @@ extern "C" int stgcn_sgd_step(float* params, const float* grads, float* momentum
 }
 
 // ------------------------------------------------------------------------------------------
+// ------------------------------------------------------------------------------------------
+// Weight packing for a whole model in one launch.  One descriptor per convolution weight (float32, the
+// reference's shapes): element (g, co, ci) is src[g*sg + co*sco + ci*sci] -- g is the adjacency partition of a
+// graph-convolution weight [K*Cout, Cin, 1, 1] or the tap of a temporal weight [Cout, Cin, kt, 1].  Written, in the
+// compute dtype, as  w[g][co][cip]  (the projection / forward operand) and  wt[g][cip][co]  (the input-gradient
+// operand), cip < Cinp zero-padded past Cin.  Either destination may be null.
+struct PackDesc {
+    const float* src; void* w; void* wt;
+    long long G, Cout, Cin, Cinp, sg, sco, sci;
+};
+
+template <typename T>
+__global__ void pack_weights_kernel(const PackDesc* table) {
+    const PackDesc d = table[blockIdx.y];
+    const long long n = d.G * d.Cout * d.Cinp;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x) {
+        const long long cip = e % d.Cinp, co = (e / d.Cinp) % d.Cout, g = e / (d.Cinp * d.Cout);
+        const float v = cip < d.Cin ? d.src[g * d.sg + co * d.sco + cip * d.sci] : 0.f;
+        if (d.w) store_elem<T>((T*)d.w, (size_t)e, v);
+        if (d.wt) store_elem<T>((T*)d.wt, (size_t)((g * d.Cinp + cip) * d.Cout + co), v);
+    }
+}
+
+// table: ndesc descriptors of 10 x 8 bytes each, in device memory; max_elems = largest G*Cout*Cinp among them
+extern "C" int stgcn_pack_weights(int dtype, const void* table, int ndesc, size_t max_elems, void* stream) {
+    if (!table || ndesc < 1 || max_elems < 1) return STGCN_ERR_ARG;
+    static_assert(sizeof(PackDesc) == 80, "descriptor layout is 10 x 8 bytes");
+    unsigned gx = (unsigned)((max_elems + 255) / 256);
+    if (gx > 1024) gx = 1024;
+    const dim3 grid(gx, (unsigned)ndesc);
+    if (dtype == STGCN_BF16) hipLaunchKernelGGL(pack_weights_kernel<bf16>, grid, dim3(256), 0, (hipStream_t)stream, (const PackDesc*)table);
+    else if (dtype == STGCN_F32) hipLaunchKernelGGL(pack_weights_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const PackDesc*)table);
+    else return STGCN_ERR_ARG;
+    return hipGetLastError() == hipSuccess ? STGCN_OK : STGCN_ERR_LAUNCH;
+}
+
 extern "C" int stgcn_version(void) { return 1; }
 extern "C" const char* stgcn_arch(void) { return "gfx950"; }
 extern "C" int stgcn_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return -1; return n; }

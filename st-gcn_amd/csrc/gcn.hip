@@ -2,7 +2,8 @@
 // and its parameter gradients, on MFMA, one skeleton frame per wave.
 //
 // gcn_fused:   out[f, a, n] = sum_k sum_b adj[k][a][b] * ( sum_c in[f, b, c] * w[k][n][c] + bias[k][n] )
-//   Forward uses adj[k][a=w][b=v] = A_eff[k][v][w], w[k][n=co][c=ci] = W[k*Cout+co][ci].
+//   Forward uses adj[k][a=w][b=v] = A_eff[k][v][w] (A_eff itself with the transposed-adjacency flag),
+//   w[k][n=co][c=ci] = W[k*Cout+co][ci].
 //   Input gradient is the same kernel with adj[k][a=v][b=w] = A_eff[k][v][w], w[k][n=ci][c=co]
 //   = W[k*Cout+co][ci] and no bias.
 //   Per (frame, 32-column tile): the projection z_k (joints x columns, 32x32 accumulator) is
@@ -21,14 +22,14 @@
 struct GcnFusedArgs {
     const void* in; const void* w; const float* adj; const float* bias; void* out; const void* add;
     double* stats;
-    int NF, V, Cin, Nout, K, ntw;
+    int NF, V, Cin, Nout, K, ntw, adj_t;
 };
 
 // Adjacency operand fragments for the chained aggregation MFMA, built in LDS once per workgroup.
 //  bf16: entry (k, s2, lane) = 8 bf16: adj[k][a = lane&31][b = acc_row(8*s2 + j, lane>>5)], j = 0..7
 //  f32 : entry (k, r, lane)  = adj[k][lane&31][acc_row(r, lane>>5)]
 template <typename T>
-__device__ __forceinline__ void build_adj_chain_table(char* tab, const float* adj, int K, int V, int tid, int nthreads) {
+__device__ __forceinline__ void build_adj_chain_table(char* tab, const float* adj, int K, int V, int tid, int nthreads, bool adj_t) {
     if constexpr (ET<T>::IS_BF16) {
         for (int e = tid; e < K * 2 * 64; e += nthreads) {
             const int lane = e & 63, s2 = (e >> 6) & 1, k = e >> 7;
@@ -37,7 +38,7 @@ __device__ __forceinline__ void build_adj_chain_table(char* tab, const float* ad
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int b = acc_row(8 * s2 + j, h);
-                f[j] = (a < V && b < V) ? adj[((size_t)k * V + a) * V + b] : 0.f;
+                f[j] = (a < V && b < V) ? adj[adj_t ? ((size_t)k * V + b) * V + a : ((size_t)k * V + a) * V + b] : 0.f;
             }
             *(i32x4*)(tab + (size_t)e * 16) = pack16<bf16>(f);
         }
@@ -46,7 +47,7 @@ __device__ __forceinline__ void build_adj_chain_table(char* tab, const float* ad
             const int lane = e & 63, r = (e >> 6) & 15, k = e >> 10;
             const int a = lane & 31, h = lane >> 5;
             const int b = acc_row(r, h);
-            ((float*)tab)[e] = (a < V && b < V) ? adj[((size_t)k * V + a) * V + b] : 0.f;
+            ((float*)tab)[e] = (a < V && b < V) ? adj[adj_t ? ((size_t)k * V + b) * V + a : ((size_t)k * V + a) * V + b] : 0.f;
         }
     }
 }
@@ -117,7 +118,7 @@ __global__ __launch_bounds__(256, 2) void gcn_fused_kernel(GcnFusedArgs a) {
             const int k = e / NC, n = nbase + (e - k * NC);
             bl[e] = (a.bias && n < Nout) ? a.bias[(size_t)k * Nout + n] : 0.f;
         }
-        build_adj_chain_table<T>(tab, a.adj, K, V, tid, 256);
+        build_adj_chain_table<T>(tab, a.adj, K, V, tid, 256, a.adj_t != 0);
     }
     __syncthreads();
 
@@ -332,13 +333,13 @@ static int gcn_fused_run(GcnFusedArgs& a, hipStream_t stream) {
     }
 }
 
-extern "C" int stgcn_gcn_fused(int dtype, const void* in, const void* w_packed, const float* adj, const float* bias,
+extern "C" int stgcn_gcn_fused(int dtype, const void* in, const void* w_packed, const float* adj, int adj_transposed, const float* bias,
                                void* out, const void* add, double* stats,
                                int NF, int V, int Cin, int Nout, int K, void* stream) {
     if (!in || !w_packed || !adj || !out) return STGCN_ERR_ARG;
     GcnFusedArgs a;
     a.in = in; a.w = w_packed; a.adj = adj; a.bias = bias; a.out = out; a.add = add; a.stats = stats;
-    a.NF = NF; a.V = V; a.Cin = Cin; a.Nout = Nout; a.K = K; a.ntw = 1;
+    a.NF = NF; a.V = V; a.Cin = Cin; a.Nout = Nout; a.K = K; a.ntw = 1; a.adj_t = adj_transposed;
     if (dtype == STGCN_BF16) return gcn_fused_run<bf16>(a, (hipStream_t)stream);
     if (dtype == STGCN_F32) return gcn_fused_run<float>(a, (hipStream_t)stream);
     return STGCN_ERR_ARG;
@@ -523,6 +524,17 @@ __global__ __launch_bounds__(256, 2) void gcn_agrad_kernel(GcnAgradArgs a) {
                     a.slab[((part * K + k) * V + v) * V + w] = red[e] + red[16 * 64 + e] + red[2 * 16 * 64 + e] + red[3 * 16 * 64 + e];
             }
         }
+    }
+}
+
+// sum of the partials [nparts][n1 + n2] into out1[n1] and out2[n2] (out2 may be null)
+__global__ void sum_parts2_kernel(const float* slab, float* out1, size_t n1, float* out2, size_t n2, int nparts) {
+    const size_t n = n1 + n2;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int p = 0; p < nparts; ++p) s += slab[(size_t)p * n + i];
+        if (i < n1) out1[i] = s;
+        else if (out2) out2[i - n1] = s;
     }
 }
 
@@ -770,6 +782,7 @@ __global__ __launch_bounds__(256) void gcn_wgrad_kernel(GcnWgradArgs a) {
 struct GcnWgradWideArgs {
     const void* x; const void* dy; const float* adj; float* slabW; float* slabB;
     int NF, V, Cin, Cout, K, cit, nci, FB, frames_per_wg;
+    size_t part_stride;      // floats per workgroup partial: K*Cout*Cin weight sums, then K*Cout bias sums
 };
 
 constexpr int GW_MAXD = 2, GW_MAXX = 4;          // staged 16-byte pieces per thread per batch (dy, x)
@@ -928,13 +941,13 @@ __global__ __launch_bounds__(768) void gcn_wgrad_wide_kernel(GcnWgradWideArgs a)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int co = c0 + cot * 32 + acc_row(r, h);
-                    if (co < Cout && ci < Cin) a.slabW[((part * K + k) * Cout + co) * Cin + ci] = accw[it][r];
+                    if (co < Cout && ci < Cin) a.slabW[part * a.part_stride + ((size_t)k * Cout + co) * Cin + ci] = accw[it][r];
                 }
             }
         }
         const float sb = dbacc + __shfl_xor(dbacc, 32);
         const int co = c0 + cot * 32 + l31;
-        if (a.slabB && cig == 0 && h == 0 && co < Cout) a.slabB[(part * K + k) * Cout + co] = sb;
+        if (cig == 0 && h == 0 && co < Cout) a.slabB[part * a.part_stride + (size_t)k * Cout + co] = sb;
     }
 }
 
@@ -965,7 +978,8 @@ static int gcn_wgrad_wide_try(const void* x, const void* dy, const float* adj, f
     gx = ceil_div_i(NF, fpw);
     a.frames_per_wg = fpw;
     a.slabW = (float*)ws;
-    a.slabB = db ? a.slabW + (size_t)gx * nW : nullptr;
+    a.part_stride = nW + nB;
+    a.slabB = a.slabW + nW;                               // bias sums follow the weight sums inside every partial
     const void* fn = a.nci == 1 ? (const void*)gcn_wgrad_wide_kernel<1> : a.nci == 2 ? (const void*)gcn_wgrad_wide_kernel<2> : (const void*)gcn_wgrad_wide_kernel<4>;
     static bool set[3] = {false, false, false};
     const int si = a.nci == 1 ? 0 : a.nci == 2 ? 1 : 2;
@@ -975,12 +989,10 @@ static int gcn_wgrad_wide_try(const void* x, const void* dy, const float* adj, f
     else if (a.nci == 2) hipLaunchKernelGGL(gcn_wgrad_wide_kernel<2>, grid, block, lds, stream, a);
     else hipLaunchKernelGGL(gcn_wgrad_wide_kernel<4>, grid, block, lds, stream, a);
     if (hipGetLastError() != hipSuccess) return STGCN_ERR_LAUNCH;
-    const int leftW = fold_parts(a.slabW, gx, nW, stream);
-    hipLaunchKernelGGL(sum_parts_kernel, dim3((unsigned)((nW + 255) / 256)), dim3(256), 0, stream, a.slabW, dW, leftW, nW);
-    if (db) {
-        const int leftB = fold_parts(a.slabB, gx, nB, stream);
-        hipLaunchKernelGGL(sum_parts_kernel, dim3((unsigned)((nB + 255) / 256)), dim3(256), 0, stream, a.slabB, db, leftB, nB);
-    }
+    // one reduction over the combined partials, written to the two outputs
+    const size_t n = nW + nB;
+    const int left = fold_parts(a.slabW, gx, n, stream);
+    hipLaunchKernelGGL(sum_parts2_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a.slabW, dW, nW, db, nB, left);
     return hipGetLastError() == hipSuccess ? STGCN_OK : STGCN_ERR_LAUNCH;
 }
 

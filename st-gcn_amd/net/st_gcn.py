@@ -51,6 +51,30 @@ class Model(nn.Module):
             self.edge_importance = [1] * len(self.st_gcn_networks)
 
         self.fcn = nn.Conv2d(256, num_class, kernel_size=1)
+        self._packer = None
+
+    def _pack_specs(self, dtype):
+        specs = []
+        for blk in self.st_gcn_networks:
+            cin_p = P.pad_to(blk.in_channels, P.kstep(dtype))
+            specs.append((blk.gcn.conv.weight, "gcn", blk.gcn.kernel_size, cin_p))
+            specs.append((blk.tcn[2].weight, "conv", 0, 0))
+            if blk.residual_kind == "conv":
+                specs.append((blk.residual[0].weight, "conv", 0, 0))
+        return specs
+
+    def _packed_weights(self, dtype, device):
+        """All blocks' convolution weights in kernel layout and compute dtype: one launch per forward pass."""
+        specs = self._pack_specs(dtype)
+        pk = self._packer
+        if pk is None or pk.dtype != dtype or pk.buf.device != device or not pk.valid(specs):
+            pk = self._packer = P.WeightPacker(specs, dtype, device)
+        pk.refresh()
+        out = []
+        for blk in self.st_gcn_networks:
+            res = pk.get(blk.residual[0].weight) if blk.residual_kind == "conv" else None
+            out.append((pk.get(blk.gcn.conv.weight), pk.get(blk.tcn[2].weight), res))
+        return out
 
     def _trunk(self, x, pool_last=False):
         N, C, T, V, M = x.size()
@@ -58,14 +82,17 @@ class Model(nn.Module):
         bn = self.data_bn
         h = DataBnFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, self.training, dtype,
                            P.pad_to(C, P.kstep(dtype)))
-        if self.training:
-            bn.num_batches_tracked += 1
+        packs = self._packed_weights(dtype, h.device)
+        counters = [bn.num_batches_tracked] if self.training else None
         last = len(self.st_gcn_networks) - 1
         for i, (gcn, importance) in enumerate(zip(self.st_gcn_networks, self.edge_importance)):
-            if pool_last and i == last:
-                # global average pool over (T, V) fused into the last block (st_gcn.py:85 of the reference)
-                return gcn.forward_pooled(h, self.A * importance)[1]
-            h, _ = gcn(h, self.A * importance)
+            # global average pool over (T, V) fused into the last block (st_gcn.py:85 of the reference)
+            want_pool = pool_last and i == last
+            h, pooled = gcn._run(h, self.A * importance, want_pool, packs=packs[i], counters=counters)
+            if want_pool:
+                h = pooled
+        if counters:
+            torch._foreach_add_(counters, 1)            # every BatchNorm's num_batches_tracked in one launch
         return h
 
     def forward(self, x):
@@ -130,7 +157,9 @@ class st_gcn(nn.Module):
         """-> (y, mean of y over (T, V) as float32 [B, C])."""
         return self._run(x, A, True)
 
-    def _run(self, x, A, want_pool):
+    def _run(self, x, A, want_pool, packs=None, counters=None):
+        """packs: this block's pre-packed weights (Model packs all blocks with one launch); counters: a list that
+        collects the num_batches_tracked buffers for a batched increment instead of bumping them here."""
         assert A.size(0) == self.gcn.kernel_size
         dtype = self.compute_dtype or (x.dtype if x.dtype in (torch.float32, torch.bfloat16) else torch.float32)
         cin = self.in_channels
@@ -149,10 +178,13 @@ class st_gcn(nn.Module):
         cfg = (self.stride, self.residual_kind, self.training, float(drop.p), self._seed(), cin, want_pool)
         y, pooled = StGcnBlockFn.apply(x, A, self.gcn.conv.weight, self.gcn.conv.bias, bn1.weight, bn1.bias,
                                conv.weight, conv.bias, bn2.weight, bn2.bias, *rargs,
-                               bn1.running_mean, bn1.running_var, bn2.running_mean, bn2.running_var, *rbufs, cfg)
+                               bn1.running_mean, bn1.running_var, bn2.running_mean, bn2.running_var, *rbufs, cfg, packs)
         if self.training:
-            bn1.num_batches_tracked += 1
-            bn2.num_batches_tracked += 1
+            tracked = [bn1.num_batches_tracked, bn2.num_batches_tracked]
             if self.residual_kind == "conv":
-                self.residual[1].num_batches_tracked += 1
+                tracked.append(self.residual[1].num_batches_tracked)
+            if counters is not None:
+                counters.extend(tracked)
+            else:
+                torch._foreach_add_(tracked, 1)
         return y, pooled

@@ -42,7 +42,7 @@ class GraphConvFn(torch.autograd.Function):
             if bias is not None:
                 bias = torch.nn.functional.pad(bias.reshape(K, Cout), (0, cout_p - Cout)).reshape(-1)
         wp = P.pack_gcn_w(Wd, K, cin_p, dtype)
-        y = P.gcn_fused(x, wp, A32.transpose(1, 2).contiguous(), cout_p, bias=None if bias is None else bias.contiguous())
+        y = P.gcn_fused(x, wp, A32.contiguous(), cout_p, bias=None if bias is None else bias.contiguous(), adj_t=True)
         if cout_p != Cout:
             y = P.cl(y[:, :Cout])
         ctx.save_for_backward(x, A32, W, b if b is not None else torch.empty(0))
@@ -86,11 +86,12 @@ class GraphConvFn(torch.autograd.Function):
 class StGcnBlockFn(torch.autograd.Function):
     """One st_gcn block.  Positional tensors:
        x, A, Wg, bg, g1, b1, Wt, bt, g2, b2, Wr, br, gr, betar  (the last four None unless conv residual)
-       then running stats rm1, rv1, rm2, rv2, rmr, rvr (updated in place when training) and the config."""
+       then running stats rm1, rv1, rm2, rv2, rmr, rvr (updated in place when training), the config, and
+       optionally the pre-packed weights ((wg, wgT), (wt, wtT), (wr, wrT) or None) of a WeightPacker."""
 
     @staticmethod
     def forward(ctx, x, A, Wg, bg, g1, b1, Wt, bt, g2, b2, Wr, br, gr, betar,
-                rm1, rv1, rm2, rv2, rmr, rvr, cfg):
+                rm1, rv1, rm2, rv2, rmr, rvr, cfg, packs=None):
         P.check_act(x)
         stride, kind, training, drop_p, seed, cin_true, want_pool = cfg
         ctx.set_materialize_grads(False)
@@ -107,19 +108,21 @@ class StGcnBlockFn(torch.autograd.Function):
         f32 = lambda t: None if t is None else t.detach().float().contiguous()
         stats = torch.zeros((3, 2 * Cout), dtype=torch.float64, device=dev) if training else None
 
-        wp = P.pack_gcn_w(Wg.detach(), K, cin_p, dtype)
-        y = P.gcn_fused(x, wp, A32.transpose(1, 2).contiguous(), Cout, bias=f32(bg), stats=stats[0] if training else None)
+        if packs is None:
+            packs = ((P.pack_gcn_w(Wg.detach(), K, cin_p, dtype), P.pack_gcn_wt(Wg.detach(), K, cin_p, dtype)),
+                     (P.pack_conv_w(Wt.detach(), dtype), P.pack_conv_wt(Wt.detach(), dtype)),
+                     (P.pack_conv_w(Wr.detach(), dtype), P.pack_conv_wt(Wr.detach(), dtype)) if kind == "conv" else None)
+        ctx.packs = packs
+        y = P.gcn_fused(x, packs[0][0], A32, Cout, bias=f32(bg), stats=stats[0] if training else None, adj_t=True)
         bn1 = P.bn_finalize(stats[0] if training else None, B * T * V, f32(g1), f32(b1), rm1, rv1, training)
 
-        wtp = P.pack_conv_w(Wt.detach(), dtype)
-        o = P.conv_rows(y, wtp, Cout, To, bias=f32(bt), pro=(bn1.scale, bn1.shift), stats=stats[1] if training else None,
+        o = P.conv_rows(y, packs[1][0], Cout, To, bias=f32(bt), pro=(bn1.scale, bn1.shift), stats=stats[1] if training else None,
                         ntaps=kt, stride=stride, pad=pad)
         bn2 = P.bn_finalize(stats[1] if training else None, B * To * V, f32(g2), f32(b2), rm2, rv2, training)
 
         r, bnr = None, None
         if kind == "conv":
-            wrp = P.pack_conv_w(Wr.detach(), dtype)
-            r = P.conv_rows(x, wrp, Cout, To, bias=f32(br), stats=stats[2] if training else None, ntaps=1, stride=stride, pad=0)
+            r = P.conv_rows(x, packs[2][0], Cout, To, bias=f32(br), stats=stats[2] if training else None, ntaps=1, stride=stride, pad=0)
             bnr = P.bn_finalize(stats[2] if training else None, B * To * V, f32(gr), f32(betar), rmr, rvr, training)
             res = r
         elif kind == "identity":
@@ -144,6 +147,7 @@ class StGcnBlockFn(torch.autograd.Function):
         x, A32, y, o, out, r, Wg, bg, g1, Wt, g2, Wr, gr = ctx.saved_tensors
         stride, kind, training, p, seed, cin_true, kt, pad = ctx.cfg
         bn1, bn2, bnr = ctx.bn
+        packs = ctx.packs
         dtype = x.dtype
         B, cin_p, T, V = x.shape
         K = A32.shape[0]
@@ -151,7 +155,7 @@ class StGcnBlockFn(torch.autograd.Function):
         To = o.shape[2]
         dev = x.device
         if dout is None and dpooled is None:
-            return (None,) * 21
+            return (None,) * 22
         if dout is not None:
             dout = P.cl(dout.to(dtype))
         dpool = None
@@ -170,8 +174,7 @@ class StGcnBlockFn(torch.autograd.Function):
         # the ReLU mask and the BN1-backward sums
         dWt = P.conv_wgrad(y, dO, kt, stride, pad, pro=(bn1.scale, bn1.shift))
         stats1 = torch.zeros((2 * Cout,), dtype=torch.float64, device=dev)
-        wtt = P.pack_conv_wt(Wt.detach(), dtype)
-        gh = P.conv_rows(dO, wtt, Cout, T, epilogue=L.EPI_RELU_BWD, aux=y, ep=(bn1.scale, bn1.shift, bn1.mean, bn1.rstd),
+        gh = P.conv_rows(dO, packs[1][1], Cout, T, epilogue=L.EPI_RELU_BWD, aux=y, ep=(bn1.scale, bn1.shift, bn1.mean, bn1.rstd),
                          stats=stats1, ntaps=kt, stride=stride, pad=pad, transposed=True)
         dg1, db1 = P.stats_to_grads(stats1, Cout)
         if CAPTURE is not None:
@@ -186,19 +189,16 @@ class StGcnBlockFn(torch.autograd.Function):
             dgr, dbetar = P.stats_to_grads(statsr, Cout)
             dbr_f = dbr.float()
             dWr = P.conv_wgrad(x, dR, 1, stride, 0)
-            wrt = P.pack_conv_wt(Wr.detach(), dtype)
-            add = P.conv_rows(dR, wrt, cin_p, T, ntaps=1, stride=stride, pad=0, transposed=True)
+            add = P.conv_rows(dR, packs[2][1], cin_p, T, ntaps=1, stride=stride, pad=0, transposed=True)
 
-        wt = P.pack_gcn_wt(Wg.detach(), K, cin_p, dtype)
-        dx = P.gcn_fused(dy, wt, A32, cin_p, add=add)
+        dx = P.gcn_fused(dy, packs[0][1], A32, cin_p, add=add)
         dWp, dbg = P.gcn_wgrad(x, dy, A32, need_bias=True)
         dWg = dWp[:, :, :cin_true].reshape(Wg.shape)
         dA = None
         if ctx.needs_input_grad[1]:
-            wp = P.pack_gcn_w(Wg.detach(), K, cin_p, dtype)
-            dA = P.gcn_agrad(x, wp, f32(bg), dy)
+            dA = P.gcn_agrad(x, packs[0][0], f32(bg), dy)
         return (dx, dA, dWg, dbg, dg1, db1, dWt, dbt, dg2, db2, dWr, dbr_f, dgr, dbetar,
-                None, None, None, None, None, None, None)
+                None, None, None, None, None, None, None, None)
 
 
 class DataBnFn(torch.autograd.Function):

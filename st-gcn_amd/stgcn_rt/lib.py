@@ -22,7 +22,7 @@ _SIGS = {
     "stgcn_conv_rows": [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp,
                         _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "stgcn_conv_wgrad": [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp],
-    "stgcn_gcn_fused": [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "stgcn_gcn_fused": [_i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "stgcn_gcn_agrad": [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp],
     "stgcn_gcn_wgrad": [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp],
     "stgcn_bn_finalize": [_vp, _d, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _i, _i, _vp],
@@ -38,6 +38,7 @@ _SIGS = {
     "stgcn_head_fc_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "stgcn_head_fc_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "stgcn_pool_bwd": [_i, _vp, _vp, _i, _i, _i, _i, _vp],
+    "stgcn_pack_weights": [_i, _vp, _i, _sz, _vp],
     "stgcn_sgd_step": [_vp, _vp, _vp, _sz, _f, _f, _f, _i, _i, _f, _vp],
     "stgcn_probe_tr16": [_vp, _vp],
     "stgcn_version": [],

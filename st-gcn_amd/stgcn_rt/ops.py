@@ -116,6 +116,54 @@ def pack_conv_wt(W, dtype):
     return W[..., 0].permute(2, 1, 0).to(dtype).contiguous()
 
 
+class WeightPacker:
+    """Packs all convolution weights of a model with ONE kernel launch per refresh().
+
+    specs: list of (weight tensor, kind, K, cin_p) with kind "gcn" (weight [K*Cout, Cin, 1, 1]) or "conv"
+    (weight [Cout, Cin, kt, 1]; K and cin_p ignored).  get(weight) -> (w, wt): the tensors pack_gcn_w / pack_gcn_wt
+    or pack_conv_w / pack_conv_wt would return.  The weights are read through their storage pointers: the packer
+    must be rebuilt when a parameter is re-allocated (valid() tells)."""
+
+    def __init__(self, specs, dtype, device):
+        self.dtype = dtype
+        self._ptrs = tuple(W.data_ptr() for W, *_ in specs)
+        self._weights = [W for W, *_ in specs]
+        total, rows, shapes = 0, [], []
+        for W, kind, K, cin_p in specs:
+            if kind == "gcn":
+                G, Cout, Cin, Cinp = K, W.shape[0] // K, W.shape[1], cin_p
+                sg, sco, sci = Cout * Cin, Cin, 1
+            else:
+                Cout, Cin, G = W.shape[0], W.shape[1], W.shape[2]
+                Cinp = Cin
+                sg, sco, sci = 1, Cin * G, G
+            n = G * Cout * Cinp
+            shapes.append((G, Cout, Cinp, total, total + n))
+            rows.append([0, 0, 0, G, Cout, Cin, Cinp, sg, sco, sci])
+            total += 2 * n
+        self.buf = torch.empty(total, dtype=dtype, device=device)
+        es = self.buf.element_size()
+        self._views = {}
+        for (W, *_), row, (G, Cout, Cinp, o_w, o_wt) in zip(specs, rows, shapes):
+            n = G * Cout * Cinp
+            row[0] = W.data_ptr()
+            row[1] = self.buf.data_ptr() + o_w * es
+            row[2] = self.buf.data_ptr() + o_wt * es
+            self._views[W.data_ptr()] = (self.buf[o_w:o_w + n].view(G, Cout, Cinp), self.buf[o_wt:o_wt + n].view(G, Cinp, Cout))
+        self.max_elems = max(r[3] * r[4] * r[6] for r in rows)
+        self.table = torch.tensor(rows, dtype=torch.int64).to(device)
+        self.ndesc = len(rows)
+
+    def valid(self, specs):
+        return self._ptrs == tuple(W.data_ptr() for W, *_ in specs)
+
+    def refresh(self):
+        L.call("stgcn_pack_weights", L.dtype_code(self.dtype), L.ptr(self.table), self.ndesc, self.max_elems, L.stream_ptr())
+
+    def get(self, W):
+        return self._views[W.data_ptr()]
+
+
 # ----------------------------------------------------------------------------- kernel wrappers
 def conv_rows(x, w_packed, Cout, Tout, bias=None, pro=None, epilogue=L.EPI_PLAIN, aux=None, ep=None, stats=None,
               ntaps=1, stride=1, pad=0, dil=1, transposed=False, out=None):
@@ -143,12 +191,12 @@ def conv_wgrad(x, dout, ntaps, stride, pad, dil=1, pro=None):
     return dW
 
 
-def gcn_fused(x, w_packed, adj, Nout, bias=None, add=None, stats=None):
-    """x [B,Cin,T,V] -> [B,Nout,T,V];  adj [K][a][b] float32 (out joint a, in joint b)."""
+def gcn_fused(x, w_packed, adj, Nout, bias=None, add=None, stats=None, adj_t=False):
+    """x [B,Cin,T,V] -> [B,Nout,T,V];  adj [K][a][b] float32 (out joint a, in joint b), or [K][b][a] with adj_t."""
     B, Cin, T, V = x.shape
     K = adj.shape[0]
     out = new_act(B, Nout, T, V, x.dtype, x.device)
-    _launch((str(x.dtype), B * T, V, Cin, Nout, K, add is not None), "stgcn_gcn_fused", L.dtype_code(x.dtype), L.ptr(x), L.ptr(w_packed), L.ptr(adj), L.ptr(bias), L.ptr(out), L.ptr(add),
+    _launch((str(x.dtype), B * T, V, Cin, Nout, K, add is not None), "stgcn_gcn_fused", L.dtype_code(x.dtype), L.ptr(x), L.ptr(w_packed), L.ptr(adj), 1 if adj_t else 0, L.ptr(bias), L.ptr(out), L.ptr(add),
            L.ptr(stats), B * T, V, Cin, Nout, K, L.stream_ptr())
     return out
 

@@ -183,7 +183,7 @@ def test_gcn_kernels(rt, case, dtype):
     bd = b.to(DEV).float()
     xd, dyd = to_dev(x, dtype), to_dev(dy, dtype)
     stats = torch.zeros(2 * Cout, dtype=torch.float64, device=DEV)
-    yk = rt.gcn_fused(xd, rt.pack_gcn_w(W4, K, Cin, dtype), Ad.transpose(1, 2).contiguous(), Cout, bias=bd, stats=stats)
+    yk = rt.gcn_fused(xd, rt.pack_gcn_w(W4, K, Cin, dtype), Ad.contiguous(), Cout, bias=bd, stats=stats, adj_t=True)
     tol = TOL[dtype]
     assert rel(yk, y) < tol
     n = B * T * V

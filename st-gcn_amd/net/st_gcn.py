@@ -80,6 +80,8 @@ class Model(nn.Module):
         N, C, T, V, M = x.size()
         dtype = self.compute_dtype
         bn = self.data_bn
+        if self.training:
+            P.stats_begin(x.device)                     # one fill clears every statistic buffer of this step
         h = DataBnFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, self.training, dtype,
                            P.pad_to(C, P.kstep(dtype)))
         packs = self._packed_weights(dtype, h.device)

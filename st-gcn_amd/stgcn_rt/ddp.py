@@ -34,14 +34,29 @@ class FlatParams:
             for p, o, n in zip(params, self.offsets, self.sizes):
                 self.flat[o:o + n].copy_(p.detach().reshape(-1))
                 p.data = self.flat[o:o + n].view(p.shape)
-                p.grad = self.grad[o:o + n].view(p.shape)
+                p.grad = None
         self.steps = 0
 
+        self.views = [self.grad[o:o + n].view(p.shape) for p, o, n in zip(params, self.offsets, self.sizes)]
+
     def zero_grad(self):
-        self.grad.zero_()
-        for p, o, n in zip(self.params, self.offsets, self.sizes):
-            if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * o:
-                p.grad = self.grad[o:o + n].view(p.shape)
+        """Drops every .grad: autograd then hands each gradient over without an accumulation kernel, and
+        gather() moves a whole bucket of them into the flat buffer with one multi-tensor copy."""
+        for p in self.params:
+            p.grad = None
+
+    def gather(self, idxs):
+        """flat.grad[slot i] = params[i].grad for i in idxs (zeros where a parameter received no gradient)."""
+        dst, src = [], []
+        for i in idxs:
+            g = self.params[i].grad
+            if g is None:
+                self.views[i].zero_()
+            elif g.data_ptr() != self.views[i].data_ptr():
+                dst.append(self.views[i])
+                src.append(g)
+        if dst:
+            torch._foreach_copy_(dst, src)
 
 
 def reverse_execution_order(model):
@@ -114,19 +129,23 @@ class GradBucketer:
         return hook
 
     def _launch(self, b):
-        s, e, _ = self.buckets[b]
+        s, e, idxs = self.buckets[b]
         self.launched.append(b)
+        self.flat.gather(idxs)
         self.handles.append(dist.all_reduce(self.flat.grad[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def finish(self):
         """Launch whatever was not triggered by hooks (unused parameters), wait for all buckets.
-        Gradients hold the SUM over ranks afterwards; the optimizer divides by the world size."""
+        Gradients hold the SUM over ranks afterwards; the optimizer divides by the world size.
+        Single process: one multi-tensor copy brings every gradient into the flat buffer."""
         if self.world > 1:
             for b in range(len(self.buckets)):
                 if b not in self.launched:
                     self._launch(b)
             for h in self.handles:
                 h.wait()
+        else:
+            self.flat.gather(range(len(self.flat.params)))
         return 1.0 / self.world
 
 

@@ -106,7 +106,7 @@ class StGcnBlockFn(torch.autograd.Function):
         dev = x.device
         A32 = A.detach().to(torch.float32).contiguous()
         f32 = lambda t: None if t is None else t.detach().float().contiguous()
-        stats = torch.zeros((3, 2 * Cout), dtype=torch.float64, device=dev) if training else None
+        stats = P.stats_alloc((3, 2 * Cout), dev) if training else None
 
         if packs is None:
             packs = ((P.pack_gcn_w(Wg.detach(), K, cin_p, dtype), P.pack_gcn_wt(Wg.detach(), K, cin_p, dtype)),
@@ -173,7 +173,7 @@ class StGcnBlockFn(torch.autograd.Function):
         # temporal conv: weight grad (input = relu(bn1(y)) recomputed in the prologue), then data grad fused with
         # the ReLU mask and the BN1-backward sums
         dWt = P.conv_wgrad(y, dO, kt, stride, pad, pro=(bn1.scale, bn1.shift))
-        stats1 = torch.zeros((2 * Cout,), dtype=torch.float64, device=dev)
+        stats1 = P.stats_alloc((2 * Cout,), dev)
         gh = P.conv_rows(dO, packs[1][1], Cout, T, epilogue=L.EPI_RELU_BWD, aux=y, ep=(bn1.scale, bn1.shift, bn1.mean, bn1.rstd),
                          stats=stats1, ntaps=kt, stride=stride, pad=pad, transposed=True)
         dg1, db1 = P.stats_to_grads(stats1, Cout)
@@ -213,7 +213,7 @@ class DataBnFn(torch.autograd.Function):
         dev = x.device
         stats = None
         if training:
-            stats = torch.zeros((2 * V * Cc,), dtype=torch.float64, device=dev)
+            stats = P.stats_alloc((2 * V * Cc,), dev)
             L.call("stgcn_data_bn_stats", L.ptr(x), L.ptr(stats), N, Cc, T, V, M, L.stream_ptr())
         bn = P.bn_finalize(stats, N * M * T, gamma.detach().float().contiguous(), beta.detach().float().contiguous(),
                            rmean, rvar, training)
@@ -230,7 +230,7 @@ class DataBnFn(torch.autograd.Function):
         (x,) = ctx.saved_tensors
         N, Cc, T, V, M, cp = ctx.dims
         dx0 = P.cl(dx0)
-        stats = torch.zeros((2 * V * Cc,), dtype=torch.float64, device=x.device)
+        stats = P.stats_alloc((2 * V * Cc,), x.device)
         L.call("stgcn_data_bn_bwd", L.dtype_code(dx0.dtype), L.ptr(dx0), L.ptr(x), L.ptr(ctx.bn.mean), L.ptr(ctx.bn.rstd), L.ptr(stats),
                N, Cc, T, V, M, cp, L.stream_ptr())
         dg, db = P.stats_to_grads(stats, V * Cc)

@@ -62,6 +62,38 @@ def workspace(device, nbytes=96 << 20):
     return w
 
 
+# Zero-initialised float64 statistic buffers come out of one arena that is cleared with a single fill per training
+# step (Model.forward calls stats_begin), instead of one tiny fill kernel per BatchNorm and direction.
+_arena = {}
+
+
+def stats_begin(device, capacity=1 << 17):
+    key = (device.type, device.index)
+    a = _arena.get(key)
+    if a is None or a[0].numel() < capacity:
+        a = _arena[key] = [torch.empty(capacity, dtype=torch.float64, device=device), 0]
+    a[0].zero_()
+    a[1] = 0
+
+
+def stats_alloc(shape, device):
+    """Zeroed float64 tensor of `shape`: a slice of the step's arena when one is open, else a fresh allocation."""
+    n = 1
+    for d in shape:
+        n *= d
+    a = _arena.get((device.type, device.index))
+    if a is None or a[1] + n > a[0].numel():
+        return torch.zeros(shape, dtype=torch.float64, device=device)
+    out = a[0][a[1]:a[1] + n].view(shape)
+    a[1] += (n + 15) // 16 * 16
+    return out
+
+
+def stats_end(device):
+    """Closes the arena (later stats_alloc calls allocate on their own until the next stats_begin)."""
+    _arena.pop((device.type, device.index), None)
+
+
 def cl(x):
     return x.contiguous(memory_format=CL)
 
@@ -272,7 +304,7 @@ def block_out_bwd(dout, out, o, r, bn2, gamma2, bnr, gammar, want_g, drop_p, see
     The incoming gradient is dout (stored tensor) and/or dpool [B,C] float32, constant over (t,v)."""
     B, Cc, T, V = o.shape
     rows = B * T * V
-    acc = torch.zeros((6, Cc), dtype=torch.float64, device=o.device)
+    acc = stats_alloc((6, Cc), o.device)
     stats2, statsr, dbo, dbr = acc[0:2], acc[2:4], acc[4], acc[5]
     has_r = r is not None
     args = [L.dtype_code(o.dtype), 0, L.ptr(dout), L.ptr(dpool), T * V, L.ptr(out), L.ptr(o), L.ptr(r), L.ptr(bn2.mean), L.ptr(bn2.rstd), L.ptr(gamma2),

@@ -49,9 +49,10 @@ def _worker(rank, world, port, out):
     torch.manual_seed(0)
     net = TinyNet()
     flat = FlatParams(net, reverse_execution_order(net))
-    # views: parameters and grads alias the flat buffers
-    for p, o, n in zip(flat.params, flat.offsets, flat.sizes):
-        assert p.data_ptr() == flat.flat.data_ptr() + 4 * o and p.grad.data_ptr() == flat.grad.data_ptr() + 4 * o
+    # views: parameters alias the flat buffer; gradient slots alias the flat gradient, .grad starts empty
+    for p, v, o, n in zip(flat.params, flat.views, flat.offsets, flat.sizes):
+        assert p.data_ptr() == flat.flat.data_ptr() + 4 * o and v.data_ptr() == flat.grad.data_ptr() + 4 * o
+        assert p.grad is None and v.shape == p.shape
     # reverse execution order: fcn first, data_bn last (unused trailing)
     assert flat.params[0] is net.fcn.weight and flat.params[-1] is net.unused
     bk = GradBucketer(flat, bucket_bytes=2048)
@@ -82,6 +83,7 @@ def _worker(rank, world, port, out):
         torch.manual_seed(100 + r)
         xr, yr = torch.randn(8, 6), torch.randint(0, 5, (8,))
         torch.nn.functional.cross_entropy(net2(xr), yr).backward()
+        f2.gather(range(len(f2.params)))
         ref += f2.grad / world
     err = (avg - ref).abs().max().item()
     assert err < 1e-6, err
@@ -111,4 +113,6 @@ def test_world1_is_a_noop():
     loss = net(torch.randn(4, 6)).sum()
     loss.backward()
     assert bk.finish() == 1.0 and bk.handles == []
+    for prm, v in zip(flat.params, flat.views):     # finish() gathered every gradient into the flat buffer
+        assert torch.equal(v, prm.grad if prm.grad is not None else torch.zeros_like(v))
     assert adjust_lr(0.1, 0, [10, 50]) == 0.1 and abs(adjust_lr(0.1, 10, [10, 50]) - 0.01) < 1e-12 and abs(adjust_lr(0.1, 50, [10, 50]) - 0.001) < 1e-12

@@ -64,6 +64,19 @@ def kernel_work(key):
     return 0.0, 0.0, "hbm"
 
 
+def recorded_traffic(key):
+    """HBM-side bytes per launch of the kernel instance `key`, as measured with `rocprofv3 --pmc FETCH_SIZE` and
+    `--pmc WRITE_SIZE` (separate passes; FETCH_SIZE doubled, the gfx950 correction for 16-byte-per-lane streaming
+    reads) and recorded in bench_traffic.json next to this file; None when that instance was not measured."""
+    try:
+        with open(os.path.join(ROOT, "bench_traffic.json")) as f:
+            rec = json.load(f)
+    except (OSError, ValueError):
+        return None
+    ent = rec.get("|".join(map(str, key)))
+    return None if ent is None else ent.get("traffic_bytes")
+
+
 def cpu_baseline(n_clips, steps, threads):
     """The CPU oracle's training step (float32 torch CPU ops), bounded sample of the same workload."""
     from oracle import stgcn_oracle as O
@@ -196,7 +209,7 @@ def main():
             else:
                 ach, peak, unit = by / mean / 1e6, HBM_PEAK, "GB/s"
             roof = {"bound": bound, "achieved": round(ach, 2), "peak": peak, "unit": unit, "frac": round(ach / peak, 4),
-                    "traffic": None, "kernel": key[0].replace("stgcn_", ""), "launch": list(map(str, key[1:])),
+                    "traffic": recorded_traffic(key), "kernel": key[0].replace("stgcn_", ""), "launch": list(map(str, key[1:])),
                     "avg_launch_ms": round(mean, 4), "launches_timed": n,
                     "share_of_step": round(sum(v[2] for v in timed.values()) / (elapsed * 1e3), 3)}
         cpu = None

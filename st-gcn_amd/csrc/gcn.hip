@@ -309,11 +309,14 @@ static int gcn_fused_run(GcnFusedArgs& a, hipStream_t stream) {
     constexpr int ES = ET<T>::ES, KSTEP = ET<T>::KSTEP;
     if (a.Cin % KSTEP != 0 || a.Cin <= 0 || a.Cin > 32 * KSTEP || a.Nout <= 0 || a.Nout % ET<T>::VEC != 0 || a.K < 1 || a.K > 8 || a.V < 1 || a.V > 32 || a.NF < 1) return STGCN_ERR_ARG;
     const size_t rsw = (size_t)a.Cin * ES + 16;
+    // column tiles per workgroup (1, 2 or 4: the store phase wants a power-of-two piece count per row): the widest
+    // that keeps the LDS image within half a CU, so two workgroups (two waves per SIMD) stay resident
+    auto lds_for = [&](int n) {
+        return (size_t)a.K * n * 32 * rsw + adj_chain_table_bytes<T>(a.K) + (size_t)a.K * n * 32 * 4 + (size_t)4 * 32 * (n * 32 * ES + 16);
+    };
     int ntw = 4;
-    while (ntw > 1 && ((size_t)a.K * ntw * 32 * rsw + adj_chain_table_bytes<T>(a.K) > 72 * 1024 || (ntw - 1) * 32 >= a.Nout)) --ntw;
-    if (ntw == 3) ntw = 2;                       // the store phase wants a power-of-two piece count per row
-    const size_t lds = (size_t)a.K * ntw * 32 * rsw + adj_chain_table_bytes<T>(a.K) + (size_t)a.K * ntw * 32 * 4 +
-                       (size_t)4 * 32 * (ntw * 32 * ES + 16);
+    while (ntw > 1 && (lds_for(ntw) > 80 * 1024 || (ntw / 2) * 32 >= a.Nout)) ntw /= 2;
+    const size_t lds = lds_for(ntw);
     if (lds > 160 * 1024) return STGCN_ERR_ARG;
     a.ntw = ntw;
     const int gy = ceil_div_i(a.Nout, ntw * 32);

@@ -46,7 +46,7 @@ def make(case, dtype):
         if name == "gcn_agrad":
             return lambda: R.gcn_agrad(x, wp, bias, dy)
         return lambda: R.gcn_wgrad(x, dy, adj)
-    if name in ("conv", "conv_t", "conv_wgrad", "conv1"):
+    if name in ("conv", "conv_t", "conv_t_epi", "conv_wgrad", "conv1"):
         kt = 1 if name == "conv1" else 9
         pad = (kt - 1) // 2
         Tout = (Tin + 2 * pad - kt) // stride + 1
@@ -64,6 +64,12 @@ def make(case, dtype):
         if name == "conv_t":
             wt = R.pack_conv_wt(W, dtype)
             return lambda: R.conv_rows(do, wt, Cin, Tin, ntaps=kt, stride=stride, pad=pad, transposed=True)
+        if name == "conv_t_epi":            # data gradient fused with the ReLU mask and BatchNorm-backward sums
+            wt = R.pack_conv_wt(W, dtype)
+            mean, rstd = torch.randn((Cin,), device=DEV) * 0.1, torch.rand((Cin,), device=DEV) + 0.5
+            st = torch.zeros(2 * Cin, dtype=torch.float64, device=DEV)
+            return lambda: R.conv_rows(do, wt, Cin, Tin, epilogue=L.EPI_RELU_BWD, aux=x, ep=(sc, sh, mean, rstd), stats=st,
+                                       ntaps=kt, stride=stride, pad=pad, transposed=True)
         return lambda: R.conv_wgrad(x, do, kt, stride, pad, pro=(sc, sh))
     raise SystemExit("unknown case " + case)
 

@@ -486,7 +486,7 @@ extern "C" int stgcn_conv_wgrad(int dtype, const void* in, const void* dout, flo
     a.B = B; a.Tin = Tin; a.Tout = Tout; a.V = V; a.Cin = Cin; a.Cout = Cout;
     a.ntaps = ntaps; a.stride = stride; a.pad = pad; a.dil = dil;
     a.win_rows_max = 0; a.tiles_per_sample = 0; a.nseg = 0;
-    if (dtype == STGCN_BF16 && dil == 1 && pad == (ntaps - 1) / 2 && ntaps > 1 && B > 0 && Tin > 0 &&
+    if (dtype == STGCN_BF16 && dil == 1 && pad == (ntaps - 1) / 2 && B > 0 && Tin > 0 &&
         Tout == (Tin - 1) / stride + 1) {
         const int rc = conv_wgrad_ring_try(in, dout, dW, pro_scale, pro_shift, B, Tin, Tout, V, Cin, Cout, ntaps, stride,
                                            workspace, workspace_bytes, (hipStream_t)stream);

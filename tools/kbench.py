@@ -46,8 +46,8 @@ def make(case, dtype):
         if name == "gcn_agrad":
             return lambda: R.gcn_agrad(x, wp, bias, dy)
         return lambda: R.gcn_wgrad(x, dy, adj)
-    if name in ("conv", "conv_t", "conv_t_epi", "conv_wgrad", "conv1"):
-        kt = 1 if name == "conv1" else 9
+    if name in ("conv", "conv_t", "conv_t_epi", "conv_wgrad", "conv1", "conv1_wgrad"):
+        kt = 1 if name.startswith("conv1") else 9
         pad = (kt - 1) // 2
         Tout = (Tin + 2 * pad - kt) // stride + 1
         x = act(Cin, Tin, dtype)
@@ -70,6 +70,8 @@ def make(case, dtype):
             st = torch.zeros(2 * Cin, dtype=torch.float64, device=DEV)
             return lambda: R.conv_rows(do, wt, Cin, Tin, epilogue=L.EPI_RELU_BWD, aux=x, ep=(sc, sh, mean, rstd), stats=st,
                                        ntaps=kt, stride=stride, pad=pad, transposed=True)
+        if name == "conv1_wgrad":
+            return lambda: R.conv_wgrad(x, do, kt, stride, pad)
         return lambda: R.conv_wgrad(x, do, kt, stride, pad, pro=(sc, sh))
     raise SystemExit("unknown case " + case)
 

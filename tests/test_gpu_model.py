@@ -241,3 +241,50 @@ def test_model_dropout_and_contract(net):
     assert torch.isfinite(m2(x)).all()
     with pytest.raises(RuntimeError):
         m(x.cpu())
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+def test_trainer_steps_match_oracle(net, dtype):
+    """REC_Processor.train's iteration (processor/recognition.py:84-97) through ddp.Trainer: three SGD-nesterov steps
+    (lr 0.1, momentum 0.9, weight decay 1e-4, dropout 0) on the small NTU model, in lockstep with the oracle's
+    training loop evaluated with the kernels' ReLU decisions of the same step.  Every step re-packs the weights the
+    optimizer just changed: a stale pack or a lost gradient shows up in the second loss."""
+    mod, _ = net
+    from stgcn_rt.ddp import Trainer
+    g = O.build_graph("ntu-rgb+d", "spatial")
+    sd = O.det_state(3, 60, g["A"], True, dtype=torch.float32)
+    x = O.det_input(2, 3, 24, 25, 2, tag=777)
+    labels = torch.tensor([5, 17])
+    sd64 = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+    names = O.param_names(sd64)
+    m = mod.Model(3, 60, dict(layout="ntu-rgb+d", strategy="spatial"), True, dropout=0.0, compute_dtype=dtype).to(DEV)
+    m.load_state_dict(sd, strict=True)
+    m.train()
+    tr = Trainer(m, lr=0.1, momentum=0.9, weight_decay=1e-4, nesterov=True)
+    xd, ld = x.float().to(DEV), labels.to(DEV)
+    moms, losses, ref_losses = {}, [], []
+    for _ in range(3):
+        F = _capture()
+        losses.append(float(tr.step(xd, ld).detach()))
+        masks = _masks_from_capture(F, 10)
+        logits, cache, newb = O.model_forward(sd64, x, True, masks=masks)
+        loss, dlog = O.cross_entropy(logits, labels)
+        grads = O.model_backward(sd64, cache, dlog, True)
+        prm = {k: sd64[k] for k in names}
+        O.sgd_nesterov_step(prm, grads, moms, 0.1)
+        sd64.update(prm)
+        sd64.update(newb)
+        ref_losses.append(float(loss))
+    ltol = 1e-4 if dtype == torch.float32 else 5e-2
+    for a, b in zip(losses, ref_losses):
+        assert abs(a - b) < ltol * max(1.0, abs(b)), (losses, ref_losses)
+    assert ref_losses[2] < ref_losses[0]                     # the loop does train
+    rsd = m.state_dict()
+    worst = ("", 0.0)
+    for k in names:
+        e = rel_l2(cpu64(rsd[k]), sd64[k])
+        if e > worst[1]:
+            worst = (k, e)
+    print("worst parameter rel-L2 deviation after 3 steps:", worst, "losses", losses, ref_losses)
+    assert worst[1] < (1e-4 if dtype == torch.float32 else 5e-2), worst
+    assert int(rsd["data_bn.num_batches_tracked"]) == 3 and int(rsd["st_gcn_networks.4.residual.1.num_batches_tracked"]) == 3

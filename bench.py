@@ -119,15 +119,26 @@ def main():
     ap.add_argument("--kernel-table", action="store_true", help="print the per-kernel time table to stderr")
     args = ap.parse_args()
 
+    if os.environ.get("STGCN_BENCH_WATCHDOG"):               # debugging aid: dump every thread's stack if the run stalls
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["STGCN_BENCH_WATCHDOG"]), exit=True)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the ST-GCN HIP path has no CPU fallback")
+    ndev = torch.cuda.device_count()
+    if local >= ndev:
+        # rehearsal of the multi-process path on a box with fewer GPUs than ranks (STGCN_DIST_BACKEND=gloo)
+        local = local % max(ndev, 1)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("STGCN_DIST_BACKEND", "nccl")          # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     if args.gpus != world and rank == 0:
         print("note: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
 

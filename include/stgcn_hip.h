@@ -89,18 +89,21 @@ int stgcn_bn_finalize(const double* stats, double count, const float* gamma, con
 int stgcn_stats_to_grads(const double* stats, float* dgamma, float* dbeta, int C, void* stream);
 
 /* out = relu((scale2*o + shift2) * keep/(1-p) + res'), res' = res_scale*res + res_shift | res | 0.
+ * relu_mask (optional, rows*C/8 bytes for bf16, rows*C/4 for f32): one byte per 16-byte piece of out, bit j set
+ * when element j of the piece is positive -- the backward then reads 1/16 of the bytes of out.
  * Replaces: BatchNorm2d apply + Dropout + residual add + ReLU (net/st_gcn.py:169-170, 193-197). */
-int stgcn_block_out_fwd(int dtype, const void* o, const void* res, void* out,
+int stgcn_block_out_fwd(int dtype, const void* o, const void* res, void* out, void* relu_mask,
                         const float* scale2, const float* shift2, const float* res_scale, const float* res_shift,
                         size_t rows, int C, float drop_p, uint32_t seed, void* stream);
 
 /* Backward of the stage above.  pass 0: per-channel sums (stats2, statsr).  pass 1: dO (BatchNorm backward of the
  * main branch), dR (same for a conv residual), g (= masked incoming gradient, for an identity residual), and the
  * bias gradients of the two convolutions (dbias_*).  The incoming gradient is dout and/or dpool (float32 [B][C],
- * constant over (t,v): the gradient of the global average pool).
+ * constant over (t,v): the gradient of the global average pool).  The ReLU decisions come from relu_mask when
+ * given (then out may be null), else from out.
  * Replaces: autograd of net/st_gcn.py:169-170, 193-197 (and of F.avg_pool2d, st_gcn.py:85, for dpool). */
 int stgcn_block_out_bwd(int dtype, int pass, const void* dout, const float* dpool, size_t rows_per_sample,
-                        const void* out, const void* o, const void* r,
+                        const void* out, const void* relu_mask, const void* o, const void* r,
                         const float* mean2, const float* rstd2, const float* gamma2,
                         const float* meanr, const float* rstdr, const float* gammar,
                         double* stats2, double* statsr, void* dO, void* dR, void* g,

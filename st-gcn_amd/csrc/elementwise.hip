@@ -94,6 +94,7 @@ extern "C" int stgcn_stats_to_grads(const double* stats, float* dgamma, float* d
 struct BlockOutArgs {
     const void* o; const void* res; void* out;
     const float* s2; const float* b2; const float* sr; const float* br;
+    uint8_t* mask;       // optional: one byte per 16-byte piece, bit j = (element j of the piece > 0)
     size_t rows; int C; uint32_t seed, thr; float keep_scale;
 };
 
@@ -121,7 +122,16 @@ __global__ __launch_bounds__(256) void block_out_fwd_kernel(BlockOutArgs a) {
             if (a.res) q += fmaf(r[j], sr[j], br[j]);
             f[j] = fmaxf(q, 0.f);
         }
-        *(i32x4*)((T*)a.out + off) = pack16<T>(f);
+        const i32x4 packed = pack16<T>(f);
+        *(i32x4*)((T*)a.out + off) = packed;
+        if (a.mask) {
+            float fr[VEC];
+            unpack16<T>(packed, fr);                      // the stored (rounded) values decide
+            uint32_t bits = 0;
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) bits |= (fr[j] > 0.f ? 1u : 0u) << j;
+            a.mask[off / VEC] = (uint8_t)bits;
+        }
     }
 }
 
@@ -144,12 +154,12 @@ static inline uint32_t drop_thr(float p) {
     return (uint32_t)t;
 }
 
-extern "C" int stgcn_block_out_fwd(int dtype, const void* o, const void* res, void* out,
+extern "C" int stgcn_block_out_fwd(int dtype, const void* o, const void* res, void* out, void* relu_mask,
                                    const float* scale2, const float* shift2, const float* res_scale, const float* res_shift,
                                    size_t rows, int C, float drop_p, uint32_t seed, void* stream) {
     if (!o || !out || !scale2 || !shift2 || drop_p < 0.f || drop_p >= 1.f) return STGCN_ERR_ARG;
     BlockOutArgs a;
-    a.o = o; a.res = res; a.out = out; a.s2 = scale2; a.b2 = shift2; a.sr = res_scale; a.br = res_shift;
+    a.o = o; a.res = res; a.out = out; a.mask = (uint8_t*)relu_mask; a.s2 = scale2; a.b2 = shift2; a.sr = res_scale; a.br = res_shift;
     a.rows = rows; a.C = C; a.seed = seed; a.thr = drop_thr(drop_p); a.keep_scale = 1.f / (1.f - drop_p);
     if (dtype == STGCN_BF16) {
         if (!ew_ok<bf16>(C)) return STGCN_ERR_ARG;
@@ -167,7 +177,7 @@ extern "C" int stgcn_block_out_fwd(int dtype, const void* o, const void* res, vo
 //   statsr = [sum g,  sum g*rhat]   (only for the conv residual: rhat = (r - meanr) * rstdr)
 struct BlockOutBwdArgs {
     const void* dout; const float* dpool; size_t rows_per_sample;
-    const void* out; const void* o; const void* r;
+    const void* out; const uint8_t* mask; const void* o; const void* r;
     const float* mean2; const float* rstd2; const float* gamma2;
     const float* meanr; const float* rstdr; const float* gammar;
     double* stats2; double* statsr;
@@ -193,6 +203,20 @@ __device__ __forceinline__ void load_dout(const BlockOutBwdArgs& a, size_t row, 
     }
 }
 
+// which elements of the 16-byte piece at `off` passed the block's final ReLU: from the mask byte the forward wrote,
+// or from the stored output itself
+template <typename T>
+__device__ __forceinline__ uint32_t relu_bits(const BlockOutBwdArgs& a, size_t off) {
+    constexpr int VEC = ET<T>::VEC;
+    if (a.mask) return a.mask[off / VEC];
+    float y[VEC];
+    unpack16<T>(*(const i32x4*)((const T*)a.out + off), y);
+    uint32_t bits = 0;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) bits |= (y[j] > 0.f ? 1u : 0u) << j;
+    return bits;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void block_out_bwd_reduce_kernel(BlockOutBwdArgs a) {
     constexpr int VEC = ET<T>::VEC;
@@ -212,14 +236,14 @@ __global__ __launch_bounds__(256) void block_out_bwd_reduce_kernel(BlockOutBwdAr
         }
         for (size_t row = (size_t)blockIdx.x * m.rpi + m.rl; row < a.rows; row += (size_t)gridDim.x * m.rpi) {
             const size_t off = row * a.C + m.cv * VEC;
-            float d[VEC], y[VEC], o[VEC], r[VEC];
+            float d[VEC], o[VEC], r[VEC];
             load_dout<T>(a, row, off, m.cv, d);
-            unpack16<T>(*(const i32x4*)((const T*)a.out + off), y);
+            const uint32_t pos = relu_bits<T>(a, off);
             unpack16<T>(*(const i32x4*)((const T*)a.o + off), o);
             if (a.r) unpack16<T>(*(const i32x4*)((const T*)a.r + off), r);
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
-                const float g = y[j] > 0.f ? d[j] : 0.f;
+                const float g = (pos >> j) & 1u ? d[j] : 0.f;
                 float gd = g;
                 if (a.thr) gd = drop_keep(off + j, a.seed, a.thr) ? g * a.keep_scale : 0.f;
                 sums[0][j] += gd;
@@ -262,14 +286,14 @@ __global__ __launch_bounds__(256) void block_out_bwd_apply_kernel(BlockOutBwdArg
         }
         for (size_t row = (size_t)blockIdx.x * m.rpi + m.rl; row < a.rows; row += (size_t)gridDim.x * m.rpi) {
             const size_t off = row * a.C + m.cv * VEC;
-            float d[VEC], y[VEC], o[VEC], r[VEC], gg[VEC], dr[VEC];
+            float d[VEC], o[VEC], r[VEC], gg[VEC], dr[VEC];
             load_dout<T>(a, row, off, m.cv, d);
-            unpack16<T>(*(const i32x4*)((const T*)a.out + off), y);
+            const uint32_t pos = relu_bits<T>(a, off);
             unpack16<T>(*(const i32x4*)((const T*)a.o + off), o);
             if (a.dR) unpack16<T>(*(const i32x4*)((const T*)a.r + off), r);
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
-                const float g = y[j] > 0.f ? d[j] : 0.f;
+                const float g = (pos >> j) & 1u ? d[j] : 0.f;
                 gg[j] = g;
                 float gd = g;
                 if (a.thr) gd = drop_keep(off + j, a.seed, a.thr) ? g * a.keep_scale : 0.f;
@@ -292,17 +316,17 @@ __global__ __launch_bounds__(256) void block_out_bwd_apply_kernel(BlockOutBwdArg
 }
 
 extern "C" int stgcn_block_out_bwd(int dtype, int pass, const void* dout, const float* dpool, size_t rows_per_sample,
-                                   const void* out, const void* o, const void* r,
+                                   const void* out, const void* relu_mask, const void* o, const void* r,
                                    const float* mean2, const float* rstd2, const float* gamma2,
                                    const float* meanr, const float* rstdr, const float* gammar,
                                    double* stats2, double* statsr, void* dO, void* dR, void* g,
                                    double* dbias_o, double* dbias_r,
                                    size_t rows, int C, float drop_p, uint32_t seed, double count, int training, void* stream) {
-    if ((!dout && !dpool) || !out || !o || !mean2 || !rstd2 || !stats2) return STGCN_ERR_ARG;
+    if ((!dout && !dpool) || (!out && !relu_mask) || !o || !mean2 || !rstd2 || !stats2) return STGCN_ERR_ARG;
     if (dpool && rows_per_sample == 0) return STGCN_ERR_ARG;
     if (r && (!meanr || !rstdr || !statsr)) return STGCN_ERR_ARG;
     BlockOutBwdArgs a;
-    a.dout = dout; a.dpool = dpool; a.rows_per_sample = rows_per_sample; a.out = out; a.o = o; a.r = r; a.mean2 = mean2; a.rstd2 = rstd2; a.gamma2 = gamma2;
+    a.dout = dout; a.dpool = dpool; a.rows_per_sample = rows_per_sample; a.out = out; a.mask = (const uint8_t*)relu_mask; a.o = o; a.r = r; a.mean2 = mean2; a.rstd2 = rstd2; a.gamma2 = gamma2;
     a.meanr = meanr; a.rstdr = rstdr; a.gammar = gammar; a.stats2 = stats2; a.statsr = statsr;
     a.dO = dO; a.dR = dR; a.g = g; a.dbias_o = dbias_o; a.dbias_r = dbias_r;
     a.rows = rows; a.C = C; a.seed = seed; a.thr = drop_thr(drop_p); a.keep_scale = 1.f / (1.f - drop_p);

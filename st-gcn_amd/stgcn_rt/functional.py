@@ -130,7 +130,11 @@ class StGcnBlockFn(torch.autograd.Function):
         else:
             res = None
         p = drop_p if training else 0.0
-        out = P.block_out_fwd(o, res, bn2, bnr, p, seed)
+        if training:
+            out, relu_mask = P.block_out_fwd(o, res, bn2, bnr, p, seed, want_mask=True)
+        else:
+            out, relu_mask = P.block_out_fwd(o, res, bn2, bnr, p, seed), None
+        ctx.relu_mask = relu_mask
 
         pooled = None
         if want_pool:                                   # mean over (T, V) of the block output, float32 [B, C]
@@ -166,7 +170,7 @@ class StGcnBlockFn(torch.autograd.Function):
 
         dO, dR, g, stats2, statsr, dbo, dbr = P.block_out_bwd(
             dout, out, o, r_, bn2, f32(g2), bnr, f32(gr) if kind == "conv" else None, kind == "identity", p, seed, training,
-            dpool=dpool)
+            dpool=dpool, relu_mask=ctx.relu_mask)
         dg2, db2 = P.stats_to_grads(stats2, Cout)
         dbt = dbo.float()
 

@@ -290,24 +290,27 @@ def stats_to_grads(stats, Cc):
     return dg, dbt
 
 
-def block_out_fwd(o, res, bn2, bnr, drop_p, seed):
+def block_out_fwd(o, res, bn2, bnr, drop_p, seed, want_mask=False):
+    """-> out, or (out, relu_mask) with want_mask: one byte per 16-byte piece of out, bit j = element j positive."""
     B, Cc, T, V = o.shape
     out = new_act(B, Cc, T, V, o.dtype, o.device)
-    _launch((str(o.dtype), B * T * V, Cc, res is not None, bnr is not None), "stgcn_block_out_fwd", L.dtype_code(o.dtype), L.ptr(o), L.ptr(res), L.ptr(out), L.ptr(bn2.scale), L.ptr(bn2.shift),
+    mask = torch.empty((B * T * V * Cc * o.element_size() // 16,), dtype=torch.uint8, device=o.device) if want_mask else None
+    _launch((str(o.dtype), B * T * V, Cc, res is not None, bnr is not None), "stgcn_block_out_fwd", L.dtype_code(o.dtype), L.ptr(o), L.ptr(res), L.ptr(out), L.ptr(mask), L.ptr(bn2.scale), L.ptr(bn2.shift),
            L.ptr(bnr.scale) if bnr is not None else None, L.ptr(bnr.shift) if bnr is not None else None,
            B * T * V, Cc, float(drop_p), int(seed) & 0xFFFFFFFF, L.stream_ptr())
-    return out
+    return (out, mask) if want_mask else out
 
 
-def block_out_bwd(dout, out, o, r, bn2, gamma2, bnr, gammar, want_g, drop_p, seed, training, dpool=None):
+def block_out_bwd(dout, out, o, r, bn2, gamma2, bnr, gammar, want_g, drop_p, seed, training, dpool=None, relu_mask=None):
     """-> dO, dR (or None), g (or None), stats2 [2,C] (sum gd, sum gd*ohat), statsr, dbias_o, dbias_r (double).
-    The incoming gradient is dout (stored tensor) and/or dpool [B,C] float32, constant over (t,v)."""
+    The incoming gradient is dout (stored tensor) and/or dpool [B,C] float32, constant over (t,v).  The ReLU
+    decisions are read from relu_mask (as written by block_out_fwd) when given, else from out."""
     B, Cc, T, V = o.shape
     rows = B * T * V
     acc = stats_alloc((6, Cc), o.device)
     stats2, statsr, dbo, dbr = acc[0:2], acc[2:4], acc[4], acc[5]
     has_r = r is not None
-    args = [L.dtype_code(o.dtype), 0, L.ptr(dout), L.ptr(dpool), T * V, L.ptr(out), L.ptr(o), L.ptr(r), L.ptr(bn2.mean), L.ptr(bn2.rstd), L.ptr(gamma2),
+    args = [L.dtype_code(o.dtype), 0, L.ptr(dout), L.ptr(dpool), T * V, L.ptr(out) if relu_mask is None else None, L.ptr(relu_mask), L.ptr(o), L.ptr(r), L.ptr(bn2.mean), L.ptr(bn2.rstd), L.ptr(gamma2),
             L.ptr(bnr.mean) if has_r else None, L.ptr(bnr.rstd) if has_r else None, L.ptr(gammar) if has_r else None,
             L.ptr(stats2), L.ptr(statsr) if has_r else None, None, None, None, L.ptr(dbo), L.ptr(dbr) if has_r else None,
             rows, Cc, float(drop_p), int(seed) & 0xFFFFFFFF, float(rows), 1 if training else 0, L.stream_ptr()]
@@ -316,7 +319,7 @@ def block_out_bwd(dout, out, o, r, bn2, gamma2, bnr, gammar, want_g, drop_p, see
     dR = new_act(B, Cc, T, V, o.dtype, o.device) if has_r else None
     g = new_act(B, Cc, T, V, o.dtype, o.device) if want_g else None
     args[1] = 1
-    args[16], args[17], args[18] = L.ptr(dO), L.ptr(dR), L.ptr(g)
+    args[17], args[18], args[19] = L.ptr(dO), L.ptr(dR), L.ptr(g)
     _launch((str(o.dtype), 1, rows, Cc, has_r, want_g), "stgcn_block_out_bwd", *args)
     return dO, dR, g, stats2, (statsr if has_r else None), dbo, (dbr if has_r else None)
 

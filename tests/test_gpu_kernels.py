@@ -241,9 +241,15 @@ def test_block_out_and_bn_kernels(rt, Cc, rows_shape, dtype):
             s = q2
             resd = None
         out_ref = torch.clamp_min(s, 0)
-        out = rt.block_out_fwd(to_dev(o, dtype), resd, bn2, bnr, p, seed)
+        out, mask = rt.block_out_fwd(to_dev(o, dtype), resd, bn2, bnr, p, seed, want_mask=True)
         tol = TOL[dtype]
         assert rel(out, out_ref) < tol, (kind, p)
+        assert torch.equal(out, rt.block_out_fwd(to_dev(o, dtype), resd, bn2, bnr, p, seed))
+        # the ReLU mask: one byte per 16-byte piece of the channels-last output, bit j = element j positive
+        vec = 16 // out.element_size()
+        pos = (out.permute(0, 2, 3, 1).reshape(-1, vec) > 0).to(torch.int32)
+        want = (pos << torch.arange(vec, device=pos.device, dtype=torch.int32)).sum(1).to(torch.uint8)
+        assert torch.equal(mask, want)
 
         # backward, evaluated at the kernel's own output so the ReLU mask is identical
         outq = out.detach().to("cpu", torch.float64)
@@ -253,6 +259,10 @@ def test_block_out_and_bn_kernels(rt, Cc, rows_shape, dtype):
         dO, dR, g, stats2, statsr, dbo, dbr = rt.block_out_bwd(
             to_dev(dout, dtype), out, to_dev(o, dtype), to_dev(r, dtype) if kind == "conv" else None,
             bn2, f(g2), bnr, f(gr) if kind == "conv" else None, kind == "identity", p, seed, True)
+        via_mask = rt.block_out_bwd(
+            to_dev(dout, dtype), None, to_dev(o, dtype), to_dev(r, dtype) if kind == "conv" else None,
+            bn2, f(g2), bnr, f(gr) if kind == "conv" else None, kind == "identity", p, seed, True, relu_mask=mask)
+        assert torch.equal(via_mask[0], dO) and (g is None or torch.equal(via_mask[2], g))
         assert rel(dO, do_ref) < tol * 2, (kind, p)
         assert rel(stats2.cpu()[1], dg2_ref) < tol * 2 and rel(stats2.cpu()[0], db2_ref) < tol * 2
         if kind == "identity":

@@ -56,7 +56,9 @@ def kernel_work(key):
     if name == "stgcn_block_out_bwd":
         rows, C, has_r = key[3], key[4], key[5]
         p = key[2]
-        n = (4 if has_r else 3) + (0 if p == 0 else (2 if has_r else 1) + (1 if len(key) > 6 and key[6] else 0))
+        want_g = len(key) > 6 and key[6]
+        # read: dout, o (+ r) and the ReLU bit mask (1/16 of a tensor); the apply pass also writes dO (+ dR) (+ g)
+        n = (3 if has_r else 2) + 1.0 / 16 + (0 if p == 0 else (2 if has_r else 1) + (1 if want_g else 0))
         return 0.0, rows * C * es * n, "hbm"
     if name == "stgcn_bn_bwd_apply":
         _, dt, rows, C = key

@@ -512,13 +512,29 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(const T* feat, float* poo
 #pragma unroll
     for (int j = 0; j < VEC; ++j) s[j] = 0.f;
     const int b = blockIdx.x;
-    if (m.active)
-        for (int row = m.rl; row < R; row += m.rpi) {
+    if (m.active) {
+        // 8 independent loads in flight per thread: one workgroup streams a whole sample, so latency is what counts
+        const T* base = feat + (size_t)b * R * C + m.cv * VEC;
+        int row = m.rl;
+        for (; row + 7 * m.rpi < R; row += 8 * m.rpi) {
+            i32x4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = *(const i32x4*)(base + (size_t)(row + u * m.rpi) * C);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                float f[VEC];
+                unpack16<T>(v[u], f);
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) s[j] += f[j];
+            }
+        }
+        for (; row < R; row += m.rpi) {
             float f[VEC];
-            unpack16<T>(*(const i32x4*)(feat + ((size_t)b * R + row) * C + m.cv * VEC), f);
+            unpack16<T>(*(const i32x4*)(base + (size_t)row * C), f);
 #pragma unroll
             for (int j = 0; j < VEC; ++j) s[j] += f[j];
         }
+    }
     __shared__ float red[256 * VEC];
 #pragma unroll
     for (int j = 0; j < VEC; ++j) red[threadIdx.x * VEC + j] = m.active ? s[j] : 0.f;

@@ -23,7 +23,9 @@ struct ConvWgradArgs {
 
 constexpr int CW_RS = 144;
 
-template <typename T, int MAXT>
+// NPW = window pieces (16 bytes) per thread: the window of the NEXT tile is fetched into registers while the current
+// tile's MFMAs run, so its load latency is hidden.
+template <typename T, int MAXT, int NPW>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvWgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int ES = ET<T>::ES;
@@ -50,68 +52,89 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvWgradArgs a) {
     // tr-read lane roles (bf16): block row q, column quad p, 16-column half g1
     const int q4 = (lane & 15) >> 2, p4 = lane & 3, g1 = (lane >> 4) & 1;
 
-    const int ntiles = a.B * a.tiles_per_sample;
-    for (int g = blockIdx.x; g < ntiles; g += a.nseg) {
-        const int b = g / a.tiles_per_sample;
-        const int tile = g - b * a.tiles_per_sample;
-        const int r0 = tile * 128, r1 = min(r0 + 128, Rout);
-        const int tlo = r0 / V, thi = (r1 - 1) / V;
-        const int flo = a.stride * tlo - a.pad;                              // may be negative
-        const int fhi = a.stride * thi - a.pad + (a.ntaps - 1) * a.dil;      // may exceed Tin-1
-        const int wrows = (fhi - flo + 1) * V;
+    // staging role: fixed 16-byte segment per thread; rows tid>>3 + 32*i
+    const int sseg = tid & 7, srow = tid >> 3;
+    float psc[VEC], psh[VEC];
+    const bool has_pro = a.pro_scale != nullptr;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+        psc[j] = has_pro ? a.pro_scale[ci0 + sseg * VEC + j] : 1.f;
+        psh[j] = has_pro ? a.pro_shift[ci0 + sseg * VEC + j] : 0.f;
+    }
+    const bool co_ok = co0 + sseg * VEC < a.Cout;
 
-        __syncthreads();     // previous tile fully consumed
+    const int ntiles = a.B * a.tiles_per_sample;
+    i32x4 dreg[4], wreg[NPW];
+    unsigned wok = 0;                                    // bit i: wreg[i] holds a row inside [0, Tin)
+    auto geom = [&](int g, int& b, int& r0, int& r1, int& tlo, int& flo, int& wrows) {
+        b = g / a.tiles_per_sample;
+        const int tile = g - b * a.tiles_per_sample;
+        r0 = tile * 128; r1 = min(r0 + 128, Rout);
+        tlo = r0 / V;
+        const int thi = (r1 - 1) / V;
+        flo = a.stride * tlo - a.pad;                                        // may be negative
+        const int fhi = a.stride * thi - a.pad + (a.ntaps - 1) * a.dil;      // may exceed Tin-1
+        wrows = (fhi - flo + 1) * V;
+    };
+    auto fetch = [&](int g) {
+        int b, r0, r1, tlo, flo, wrows;
+        geom(g, b, r0, r1, tlo, flo, wrows);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = srow + 32 * i;
+            dreg[i] = zero16();
+            if (r0 + row < r1 && co_ok)
+                dreg[i] = *(const i32x4*)((const char*)a.dout + (((size_t)b * Rout + r0 + row) * a.Cout + co0 + sseg * VEC) * ES);
+        }
+        wok = 0;
+#pragma unroll
+        for (int i = 0; i < NPW; ++i) {
+            const int row = srow + 32 * i;
+            wreg[i] = zero16();
+            if (row < wrows) {
+                const int fr = row / V;
+                const int f = flo + fr;
+                if (f >= 0 && f < a.Tin) {
+                    wok |= 1u << i;
+                    wreg[i] = *(const i32x4*)((const char*)a.in + ((((size_t)b * a.Tin + f) * V + (row - fr * V)) * a.Cin + ci0 + sseg * VEC) * ES);
+                }
+            }
+        }
+    };
+    auto commit = [&](int wrows) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *(i32x4*)(dtile + (srow + 32 * i) * CW_RS + sseg * 16) = dreg[i];
+#pragma unroll
+        for (int i = 0; i < NPW; ++i) {
+            const int row = srow + 32 * i;
+            if (row < wrows) {
+                i32x4 v = wreg[i];
+                if (has_pro && ((wok >> i) & 1u)) {
+                    float f[VEC];
+                    unpack16<T>(v, f);
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) f[j] = fmaxf(fmaf(f[j], psc[j], psh[j]), 0.f);
+                    v = pack16<T>(f);
+                }
+                *(i32x4*)(win + (size_t)row * CW_RS + sseg * 16) = v;
+            }
+        }
+    };
+
+    if ((int)blockIdx.x < ntiles) fetch(blockIdx.x);
+    for (int g = blockIdx.x; g < ntiles; g += a.nseg) {
+        int b, r0, r1, tlo, flo, wrows;
+        geom(g, b, r0, r1, tlo, flo, wrows);
+
+        lds_barrier();       // previous tile fully consumed
         if (tid < 128) {
             const int r = min(r0 + tid, r1 - 1);
             const int to = r / V;
             rb[tid] = ((a.stride * (to - tlo)) * V + (r - to * V)) * CW_RS;
         }
-        // dout tile, zero beyond the sample
-        for (int p = tid; p < 128 * 8; p += 256) {
-            const int row = p >> 3, seg = p & 7;
-            i32x4 v = zero16();
-            const int co = co0 + seg * VEC;
-            if (r0 + row < r1 && co < a.Cout)
-                v = *(const i32x4*)((const char*)a.dout + (((size_t)b * Rout + r0 + row) * a.Cout + co) * ES);
-            *(i32x4*)(dtile + row * CW_RS + seg * 16) = v;
-        }
-        // input window
-        const int npieces = wrows * 8;
-        for (int p0 = 0; p0 < npieces; p0 += 256 * 4) {
-            i32x4 v[4];
-            bool ok[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int p = p0 + u * 256 + tid;
-                ok[u] = false;
-                v[u] = zero16();
-                if (p < npieces) {
-                    const int row = p >> 3, seg = p & 7;
-                    const int f = flo + row / V;
-                    if (f >= 0 && f < a.Tin) {
-                        ok[u] = true;
-                        v[u] = *(const i32x4*)((const char*)a.in + ((((size_t)b * a.Tin + f) * V + (row % V)) * a.Cin + ci0 + seg * VEC) * ES);
-                    }
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int p = p0 + u * 256 + tid;
-                if (p < npieces) {
-                    const int row = p >> 3, seg = p & 7;
-                    if (ok[u] && a.pro_scale) {
-                        float f[VEC];
-                        unpack16<T>(v[u], f);
-                        const int c0 = ci0 + seg * VEC;
-#pragma unroll
-                        for (int j = 0; j < VEC; ++j) f[j] = fmaxf(fmaf(f[j], a.pro_scale[c0 + j], a.pro_shift[c0 + j]), 0.f);
-                        v[u] = pack16<T>(f);
-                    }
-                    *(i32x4*)(win + (size_t)row * CW_RS + seg * 16) = v[u];
-                }
-            }
-        }
-        __syncthreads();
+        commit(wrows);
+        lds_barrier();
+        if (g + a.nseg < ntiles) fetch(g + a.nseg);      // in flight during this tile's MFMAs
 
         if constexpr (BF) {
             // wave (coh, cih): all 128 rows, 8 k-steps of 16 rows
@@ -454,17 +477,19 @@ static int conv_wgrad_run(ConvWgradArgs& a, float* dW, size_t ws_bytes, hipStrea
     a.nseg = nseg;
     dim3 grid((unsigned)nseg, (unsigned)ncot, (unsigned)ncit);
     int rc;
+    const int npw = ceil_div_i(a.win_rows_max, 32);      // window pieces per thread (32 rows per staging pass)
+    if (npw > 24) return STGCN_ERR_ARG;
+#define CW_LAUNCH(MT_, NP_) do { \
+        auto kern = conv_wgrad_kernel<T, MT_, NP_>; \
+        static bool set_ = false; \
+        if (!set_) { if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return STGCN_ERR_LAUNCH; set_ = true; } \
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, a); } while (0)
     if (a.ntaps == 1) {
-        auto kern = conv_wgrad_kernel<T, 1>;
-        static bool set1 = false;
-        if (!set1) { if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return STGCN_ERR_LAUNCH; set1 = true; }
-        hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, a);
+        if (npw <= 12) CW_LAUNCH(1, 12); else CW_LAUNCH(1, 24);
     } else {
-        auto kern = conv_wgrad_kernel<T, 9>;
-        static bool set9 = false;
-        if (!set9) { if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return STGCN_ERR_LAUNCH; set9 = true; }
-        hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, a);
+        if (npw <= 12) CW_LAUNCH(9, 12); else if (npw <= 17) CW_LAUNCH(9, 17); else CW_LAUNCH(9, 24);
     }
+#undef CW_LAUNCH
     rc = hipGetLastError() == hipSuccess ? STGCN_OK : STGCN_ERR_LAUNCH;
     if (rc) return rc;
     const size_t n = (size_t)a.ntaps * a.Cout * a.Cin;

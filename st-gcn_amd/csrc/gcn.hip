@@ -664,24 +664,49 @@ __global__ __launch_bounds__(256) void gcn_wgrad_kernel(GcnWgradArgs a) {
     const int q4 = (lane & 15) >> 2, p4 = lane & 3, g1 = (lane >> 4) & 1;
     const int dppr = 32 * ES / 16, xppr = CIG * ES / 16;
 
-    for (int it0 = 0; it0 < a.iters; ++it0) {
-        const int f = (it0 * gridDim.x + blockIdx.x) * 4 + wave;
+    // The images are private to a wave, so no workgroup barrier is needed inside the frame loop; the next frame's
+    // pieces are fetched into registers while this frame's MFMAs run.
+    constexpr int DPN = ES;                      // dy pieces per lane: 32 rows x (32 channels * ES / 16) / 64
+    constexpr int XPN = 2 * ES;                  // x pieces per lane for a 64-channel group
+    i32x4 dreg[DPN], xreg[XPN];
+    auto fetch = [&](int f) {
         const bool fok = f < a.NF;
-        __syncthreads();                         // images of the previous frame fully consumed
-        for (int p = lane; p < V * dppr; p += 64) {
+#pragma unroll
+        for (int i = 0; i < DPN; ++i) {
+            const int p = lane + 64 * i;
             const int row = p / dppr, seg = p - row * dppr;
-            i32x4 v = zero16();
-            if (fok && c0 + seg * (16 / ES) < Cout)
-                v = *(const i32x4*)((const char*)a.dy + (((size_t)f * V + row) * Cout + c0) * ES + seg * 16);
-            *(i32x4*)(dimg + row * DRS + seg * 16) = v;
+            dreg[i] = zero16();
+            if (fok && row < V && c0 + seg * (16 / ES) < Cout)
+                dreg[i] = *(const i32x4*)((const char*)a.dy + (((size_t)f * V + row) * Cout + c0) * ES + seg * 16);
         }
-        for (int p = lane; p < V * xppr; p += 64) {
+#pragma unroll
+        for (int i = 0; i < XPN; ++i) {
+            const int p = lane + 64 * i;
             const int row = p / xppr, seg = p - row * xppr;
-            i32x4 v = zero16();
-            if (fok) v = *(const i32x4*)((const char*)a.x + (((size_t)f * V + row) * Cin + i0) * ES + seg * 16);
-            *(i32x4*)(ximg + row * XRS + seg * 16) = v;
+            xreg[i] = zero16();
+            if (fok && row < V) xreg[i] = *(const i32x4*)((const char*)a.x + (((size_t)f * V + row) * Cin + i0) * ES + seg * 16);
         }
-        __syncthreads();
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int i = 0; i < DPN; ++i) {
+            const int p = lane + 64 * i;
+            const int row = p / dppr, seg = p - row * dppr;
+            if (row < V) *(i32x4*)(dimg + row * DRS + seg * 16) = dreg[i];
+        }
+#pragma unroll
+        for (int i = 0; i < XPN; ++i) {
+            const int p = lane + 64 * i;
+            const int row = p / xppr, seg = p - row * xppr;
+            if (row < V) *(i32x4*)(ximg + row * XRS + seg * 16) = xreg[i];
+        }
+    };
+    fetch(blockIdx.x * 4 + wave);
+    for (int it0 = 0; it0 < a.iters; ++it0) {
+        __builtin_amdgcn_wave_barrier();         // this wave's reads of the previous images are issued (LDS is in order per wave)
+        commit();
+        __builtin_amdgcn_wave_barrier();
+        if (it0 + 1 < a.iters) fetch(((it0 + 1) * gridDim.x + blockIdx.x) * 4 + wave);
 #pragma unroll
         for (int k = 0; k < GCN_KMAX; ++k) {
             if (k < K) {

@@ -43,21 +43,24 @@ constexpr int CB_RS = 144;
 constexpr int CB_WIN_ROWS = 544;    // window capacity in rows
 constexpr int CB_BN_MAX = 128;      // widest column tile (sizes the weight buffers)
 
-template <int WR, int WC, int MT, int NT, int EPI>
+template <typename T, int WR, int WC, int MT, int NT, int EPI>
 __global__ __launch_bounds__(WR * WC * 64) void conv_big_kernel(ConvBigArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int ES = ET<T>::ES;                        // bytes per element
+    constexpr int VEC = ET<T>::VEC;                      // elements per 16-byte piece
+    constexpr int CK = 128 / ES;                         // channels per 128-byte chunk of Cin: 64 (bf16) / 32 (f32)
     constexpr int BM = WR * MT * 32;
     constexpr int NTH = WR * WC * 64;                    // threads per workgroup (256 or 512)
     constexpr int RPP = NTH / 8;                         // window rows staged per pass
     constexpr int NPF = (CB_WIN_ROWS + RPP - 1) / RPP;   // window pieces per thread
     constexpr int BN = WC * NT * 32;                     // column tile: 128 or 64 output channels
-    constexpr int EPR = BN / 8;                          // 16-byte pieces per output row of the tile
+    constexpr int EPR = BN / VEC;                        // 16-byte pieces per output row of the tile
     constexpr int WPT = BN * 8 / NTH;                    // weight-tile pieces per thread
     constexpr int ERP = NTH / EPR;                       // epilogue rows per pass
     constexpr int EPP = BM / ERP;                        // epilogue passes per tile
     constexpr int EG = EPP < 8 ? EPP : 8;                // passes whose auxiliary loads are issued together
     static_assert(BN == 128 || BN == 64, "column tile is 128 or 64");
-    constexpr int SRS = BN * 2 + 16;                  // epilogue staging row stride
+    constexpr int SRS = BN * ES + 16;                  // epilogue staging row stride
     char* win = smem;
     char* wbuf = smem + (size_t)CB_WIN_ROWS * CB_RS;     // 3 x [128][RS]
     const int ZOFF = a.zero_row * CB_RS;                 // byte offset of the all-zero row
@@ -68,7 +71,7 @@ __global__ __launch_bounds__(WR * WC * 64) void conv_big_kernel(ConvBigArgs a) {
     const int V = a.V, Cin = a.Cin, Cout = a.Cout, Tin = a.Tin, ntaps = a.ntaps;
     const int co0 = blockIdx.y * BN;
     const int Rv = a.Tv * V, Rreal = a.Tout_real * V;
-    const int nchunks = Cin / 64;
+    const int nchunks = Cin / CK;
     const int ntile_total = a.B * a.tiles_per_sample;
 
     if (tid < CB_RS / 16) *(i32x4*)(smem + ZOFF + tid * 16) = zero16();
@@ -77,11 +80,11 @@ __global__ __launch_bounds__(WR * WC * 64) void conv_big_kernel(ConvBigArgs a) {
     const int eseg = tid % EPR, erow = tid / EPR;          // epilogue: ERP rows per pass, fixed 8 channels
     const bool has_pro = a.pro_scale != nullptr;
 
-    float e_sc[8], e_sh[8], e_mu[8], e_rs[8], s1[8], s2[8];
+    float e_sc[VEC], e_sh[VEC], e_mu[VEC], e_rs[VEC], s1[VEC], s2[VEC];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
+    for (int j = 0; j < VEC; ++j) {
         s1[j] = 0.f; s2[j] = 0.f;
-        const int co = co0 + eseg * 8 + j;
+        const int co = co0 + eseg * VEC + j;
         if (EPI == 1 && co < Cout) { e_sc[j] = a.ep_scale[co]; e_sh[j] = a.ep_shift[co]; e_mu[j] = a.ep_mean[co]; e_rs[j] = a.ep_rstd[co]; }
         else { e_sc[j] = e_sh[j] = e_mu[j] = e_rs[j] = 0.f; }
     }
@@ -107,18 +110,18 @@ __global__ __launch_bounds__(WR * WC * 64) void conv_big_kernel(ConvBigArgs a) {
     };
     i32x4 pf[NPF];
     auto fetch_win = [&](int b, int flo, int wrows, int chunk) {
-        const char* base = (const char*)a.in + (((size_t)b * Tin + flo) * V * (size_t)Cin + (size_t)chunk * 64 + sseg * 8) * 2;
+        const char* base = (const char*)a.in + (((size_t)b * Tin + flo) * V * (size_t)Cin + (size_t)chunk * CK + sseg * VEC) * ES;
 #pragma unroll
         for (int i = 0; i < NPF; ++i) {
             const int row = srow + RPP * i;
-            if (row < wrows) pf[i] = *(const i32x4*)(base + (size_t)row * Cin * 2);
+            if (row < wrows) pf[i] = *(const i32x4*)(base + (size_t)row * Cin * ES);
         }
     };
     auto commit_win = [&](int wrows, int chunk) {
-        float psc[8], psh[8];
+        float psc[VEC], psh[VEC];
         if (has_pro) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { psc[j] = a.pro_scale[chunk * 64 + sseg * 8 + j]; psh[j] = a.pro_shift[chunk * 64 + sseg * 8 + j]; }
+            for (int j = 0; j < VEC; ++j) { psc[j] = a.pro_scale[chunk * CK + sseg * VEC + j]; psh[j] = a.pro_shift[chunk * CK + sseg * VEC + j]; }
         }
 #pragma unroll
         for (int i = 0; i < NPF; ++i) {
@@ -126,11 +129,11 @@ __global__ __launch_bounds__(WR * WC * 64) void conv_big_kernel(ConvBigArgs a) {
             if (row < wrows) {
                 i32x4 v = pf[i];
                 if (has_pro) {
-                    float f[8];
-                    unpack16<bf16>(v, f);
+                    float f[VEC];
+                    unpack16<T>(v, f);
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) f[j] = fmaxf(fmaf(f[j], psc[j], psh[j]), 0.f);
-                    v = pack16<bf16>(f);
+                    for (int j = 0; j < VEC; ++j) f[j] = fmaxf(fmaf(f[j], psc[j], psh[j]), 0.f);
+                    v = pack16<T>(f);
                 }
                 *(i32x4*)(win + (size_t)row * CB_RS + sseg * 16) = v;
             }
@@ -145,7 +148,7 @@ __global__ __launch_bounds__(WR * WC * 64) void conv_big_kernel(ConvBigArgs a) {
             const int n = p >> 3, sg = p & 7;
             const int co = co0 + n;
             wreg[i] = zero16();
-            if (co < Cout) wreg[i] = *(const i32x4*)((const uint16_t*)a.w + ((size_t)tap * Cout + co) * Cin + chunk * 64 + sg * 8);
+            if (co < Cout) wreg[i] = *(const i32x4*)((const char*)a.w + (((size_t)tap * Cout + co) * Cin + chunk * CK + sg * VEC) * ES);
         }
     };
     auto store_w = [&](int buf) {
@@ -223,7 +226,7 @@ __global__ __launch_bounds__(WR * WC * 64) void conv_big_kernel(ConvBigArgs a) {
 #pragma unroll
                 for (int n = 0; n < NT; ++n)
 #pragma unroll
-                    for (int m = 0; m < MT; ++m) mma_step<bf16>(acc[m][n], f.af[m], f.bf[n]);
+                    for (int m = 0; m < MT; ++m) mma_step<T>(acc[m][n], f.af[m], f.bf[n]);
             };
             Frag fa, fb;
             int aoff[MT], aoff_n[MT];
@@ -290,14 +293,16 @@ __global__ __launch_bounds__(WR * WC * 64) void conv_big_kernel(ConvBigArgs a) {
                 for (int r = 0; r < 16; ++r) {
                     const int rl = (wr * MT + m) * 32 + acc_row(r, h);
                     const int col = (wc * NT + n) * 32 + l31;
-                    const uint32_t pk = pack_bf16x2(acc[m][n][r] + biasv[n], 0.f);
-                    *(uint16_t*)(smem + (size_t)rl * SRS + col * 2) = (uint16_t)(pk & 0xFFFFu);
+                    if constexpr (ET<T>::IS_BF16)
+                        *(uint16_t*)(smem + (size_t)rl * SRS + col * 2) = (uint16_t)(pack_bf16x2(acc[m][n][r] + biasv[n], 0.f) & 0xFFFFu);
+                    else
+                        *(float*)(smem + (size_t)rl * SRS + col * 4) = acc[m][n][r] + biasv[n];
                 }
         lds_barrier();
         {
-            const bool cok = co0 + eseg * 8 < Cout;
-            const uint16_t* auxb = (const uint16_t*)a.aux + (size_t)b * Rreal * Cout + co0 + eseg * 8;
-            uint16_t* outb = (uint16_t*)a.out + (size_t)b * Rreal * Cout + co0 + eseg * 8;
+            const bool cok = co0 + eseg * VEC < Cout;
+            const T* auxb = (const T*)a.aux + (size_t)b * Rreal * Cout + co0 + eseg * VEC;
+            T* outb = (T*)a.out + (size_t)b * Rreal * Cout + co0 + eseg * VEC;
 #pragma unroll 1
             for (int g = 0; g < EPP / EG; ++g) {
                 int rrow[EG];
@@ -321,21 +326,21 @@ __global__ __launch_bounds__(WR * WC * 64) void conv_big_kernel(ConvBigArgs a) {
                     if (rrow[i] >= 0) {
                         const int rl = erow + ERP * (g * EG + i);
                         i32x4 v = *(const i32x4*)(smem + (size_t)rl * SRS + eseg * 16);
-                        float f[8];
-                        unpack16<bf16>(v, f);
+                        float f[VEC];
+                        unpack16<T>(v, f);
                         if constexpr (EPI == 1) {
-                            float y[8];
-                            unpack16<bf16>(av[i], y);
+                            float y[VEC];
+                            unpack16<T>(av[i], y);
 #pragma unroll
-                            for (int j = 0; j < 8; ++j) {
+                            for (int j = 0; j < VEC; ++j) {
                                 f[j] = (fmaf(y[j], e_sc[j], e_sh[j]) > 0.f) ? f[j] : 0.f;
                                 s1[j] += f[j];
                                 s2[j] += f[j] * ((y[j] - e_mu[j]) * e_rs[j]);
                             }
-                            v = pack16<bf16>(f);
+                            v = pack16<T>(f);
                         } else {
 #pragma unroll
-                            for (int j = 0; j < 8; ++j) { s1[j] += f[j]; s2[j] += f[j] * f[j]; }
+                            for (int j = 0; j < VEC; ++j) { s1[j] += f[j]; s2[j] += f[j] * f[j]; }
                         }
                         *(i32x4*)(outb + (size_t)rrow[i] * Cout) = v;
                     }
@@ -349,11 +354,11 @@ __global__ __launch_bounds__(WR * WC * 64) void conv_big_kernel(ConvBigArgs a) {
         __syncthreads();
         float* red = (float*)smem;                        // [NTH][16]
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { red[tid * 16 + j] = s1[j]; red[tid * 16 + 8 + j] = s2[j]; }
+        for (int j = 0; j < VEC; ++j) { red[tid * 16 + j] = s1[j]; red[tid * 16 + 8 + j] = s2[j]; }
         __syncthreads();
         if (tid < 2 * BN) {
             const int which = tid / BN, c = tid % BN;     // which: 0 = s1, 1 = s2 ; c = channel within the tile
-            const int sg = c >> 3, j = c & 7;
+            const int sg = c / VEC, j = c % VEC;
             float t = 0.f;
             for (int r = 0; r < ERP; ++r) t += red[(r * EPR + sg) * 16 + which * 8 + j];
             if (co0 + c < Cout) atomicAdd(&a.stats[which * Cout + co0 + c], (double)t);
@@ -361,7 +366,7 @@ __global__ __launch_bounds__(WR * WC * 64) void conv_big_kernel(ConvBigArgs a) {
     }
 }
 
-template <int WR, int WC, int MT, int NT, int EPI>
+template <typename T, int WR, int WC, int MT, int NT, int EPI>
 static int launch_conv_big(ConvBigArgs& a, hipStream_t stream) {
     constexpr int BM = WR * MT * 32;
     a.tiles_per_sample = ceil_div_i(a.Tv * a.V, BM);
@@ -372,7 +377,7 @@ static int launch_conv_big(ConvBigArgs& a, hipStream_t stream) {
     const int nct = ceil_div_i(a.Cout, BN);
     int gx = max(1, 256 / nct);
     if (gx > a.B * a.tiles_per_sample) gx = a.B * a.tiles_per_sample;
-    auto kern = conv_big_kernel<WR, WC, MT, NT, EPI>;
+    auto kern = conv_big_kernel<T, WR, WC, MT, NT, EPI>;
     static bool set = false;
     if (!set) { if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return STGCN_ERR_LAUNCH; set = true; }
     hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)nct), dim3(WR * WC * 64), lds, stream, a);
@@ -388,6 +393,7 @@ static int conv_big_win_rows(const ConvBigArgs& a, int BM) {
 }
 
 // dry = true: only report whether the shape fits (0) or not (-1)
+template <typename T>
 static int conv_big_launch_any(ConvBigArgs& a, int epi, hipStream_t stream, bool dry) {
     a.foff_min = 0; a.foff_max = 0;
     for (int i = 0; i < a.ntaps; ++i) {
@@ -401,24 +407,29 @@ static int conv_big_launch_any(ConvBigArgs& a, int epi, hipStream_t stream, bool
     const bool fit256 = conv_big_win_rows(a, 256) <= CB_WIN_ROWS;
     const bool fit128 = conv_big_win_rows(a, 128) <= CB_WIN_ROWS;
     if (dry) return (fit256 || fit128) ? 0 : -1;
-    const bool narrow = a.Cout <= 64;                      // 64-channel column tile: 8 waves of 32 rows x 64 channels
+    // 64-channel column tiles (8 waves of 32 rows x 64 channels) for narrow outputs, and always in f32, whose
+    // epilogue staging rows are twice as wide
+    const bool narrow = a.Cout <= 64 || !ET<T>::IS_BF16;
     if (fit256 && (waste256 <= waste128 + 0.10 || !fit128)) {
-        if (narrow) return epi == 1 ? launch_conv_big<8, 1, 1, 2, 1>(a, stream) : launch_conv_big<8, 1, 1, 2, 0>(a, stream);
-        return epi == 1 ? launch_conv_big<4, 2, 2, 2, 1>(a, stream) : launch_conv_big<4, 2, 2, 2, 0>(a, stream);
+        if (narrow) return epi == 1 ? launch_conv_big<T, 8, 1, 1, 2, 1>(a, stream) : launch_conv_big<T, 8, 1, 1, 2, 0>(a, stream);
+        if constexpr (ET<T>::IS_BF16)
+            return epi == 1 ? launch_conv_big<T, 4, 2, 2, 2, 1>(a, stream) : launch_conv_big<T, 4, 2, 2, 2, 0>(a, stream);
     }
     if (fit128) {
-        if (narrow) return epi == 1 ? launch_conv_big<4, 1, 1, 2, 1>(a, stream) : launch_conv_big<4, 1, 1, 2, 0>(a, stream);
-        return epi == 1 ? launch_conv_big<4, 2, 1, 2, 1>(a, stream) : launch_conv_big<4, 2, 1, 2, 0>(a, stream);
+        if (narrow) return epi == 1 ? launch_conv_big<T, 4, 1, 1, 2, 1>(a, stream) : launch_conv_big<T, 4, 1, 1, 2, 0>(a, stream);
+        if constexpr (ET<T>::IS_BF16)
+            return epi == 1 ? launch_conv_big<T, 4, 2, 1, 2, 1>(a, stream) : launch_conv_big<T, 4, 2, 1, 2, 0>(a, stream);
     }
     return -1;
 }
 
 // Returns -1 when the shape is outside this kernel's domain (the caller then uses conv_rows).
-int conv_big_try(const void* in, const void* w, void* out, const float* bias, const float* pro_scale, const float* pro_shift,
-                 int epilogue, const void* aux, const float* ep_scale, const float* ep_shift, const float* ep_mean, const float* ep_rstd,
-                 double* stats, int B, int Tin, int Tout, int V, int Cin, int Cout, int ntaps, int stride, int pad, int dil,
-                 int transposed, hipStream_t stream) {
-    if (Cin % 64 != 0 || Cin <= 0 || Cout % 8 != 0 || V < 1 || V > 32 || ntaps < 1 || ntaps > 9 || dil != 1 || (stride != 1 && stride != 2)) return -1;
+template <typename T>
+static int conv_big_try_t(const void* in, const void* w, void* out, const float* bias, const float* pro_scale, const float* pro_shift,
+                          int epilogue, const void* aux, const float* ep_scale, const float* ep_shift, const float* ep_mean, const float* ep_rstd,
+                          double* stats, int B, int Tin, int Tout, int V, int Cin, int Cout, int ntaps, int stride, int pad, int dil,
+                          int transposed, hipStream_t stream) {
+    if (Cin % (128 / ET<T>::ES) != 0 || Cin <= 0 || Cout % ET<T>::VEC != 0 || V < 1 || V > 32 || ntaps < 1 || ntaps > 9 || dil != 1 || (stride != 1 && stride != 2)) return -1;
     ConvBigArgs a;
     a.in = in; a.w = w; a.out = out; a.bias = bias; a.pro_scale = pro_scale; a.pro_shift = pro_shift;
     a.aux = aux; a.ep_scale = ep_scale; a.ep_shift = ep_shift; a.ep_mean = ep_mean; a.ep_rstd = ep_rstd; a.stats = stats;
@@ -427,7 +438,7 @@ int conv_big_try(const void* in, const void* w, void* out, const float* bias, co
     if (!transposed || stride == 1) {
         a.fs = transposed ? 1 : stride; a.os = 1; a.opar = 0; a.Tv = Tout; a.ntaps = ntaps;
         for (int i = 0; i < ntaps; ++i) { a.foff[i] = transposed ? pad - i : i - pad; a.wk[i] = i; }
-        return conv_big_launch_any(a, epilogue, stream, false);
+        return conv_big_launch_any<T>(a, epilogue, stream, false);
     }
     // transposed, stride 2: one launch per output-frame parity
     for (int pass = 0; pass < 2; ++pass) {               // pass 0 checks both parities fit, pass 1 launches
@@ -438,9 +449,22 @@ int conv_big_try(const void* in, const void* w, void* out, const float* bias, co
                 const int num = par + pad - k;
                 if ((num & 1) == 0) { a.foff[a.ntaps] = num / 2; a.wk[a.ntaps] = k; ++a.ntaps; }
             }
-            const int rc = conv_big_launch_any(a, epilogue, stream, pass == 0);
+            const int rc = conv_big_launch_any<T>(a, epilogue, stream, pass == 0);
             if (rc != STGCN_OK) return rc;
         }
     }
     return STGCN_OK;
+}
+
+int conv_big_try(int dtype, const void* in, const void* w, void* out, const float* bias, const float* pro_scale, const float* pro_shift,
+                 int epilogue, const void* aux, const float* ep_scale, const float* ep_shift, const float* ep_mean, const float* ep_rstd,
+                 double* stats, int B, int Tin, int Tout, int V, int Cin, int Cout, int ntaps, int stride, int pad, int dil,
+                 int transposed, hipStream_t stream) {
+    if (dtype == STGCN_BF16)
+        return conv_big_try_t<bf16>(in, w, out, bias, pro_scale, pro_shift, epilogue, aux, ep_scale, ep_shift, ep_mean, ep_rstd,
+                                    stats, B, Tin, Tout, V, Cin, Cout, ntaps, stride, pad, dil, transposed, stream);
+    if (dtype == STGCN_F32)
+        return conv_big_try_t<float>(in, w, out, bias, pro_scale, pro_shift, epilogue, aux, ep_scale, ep_shift, ep_mean, ep_rstd,
+                                     stats, B, Tin, Tout, V, Cin, Cout, ntaps, stride, pad, dil, transposed, stream);
+    return -1;
 }

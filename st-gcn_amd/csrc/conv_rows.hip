@@ -274,8 +274,8 @@ int conv_t9_try(const void* in, const void* w, void* out, const float* bias, con
                 int epilogue, const void* aux, const float* ep_scale, const float* ep_shift, const float* ep_mean, const float* ep_rstd,
                 double* stats, int B, int T, int V, int Cin, int Cout, int ntaps, int transposed, hipStream_t stream);
 
-// tiled path for the remaining bf16 shapes with Cin a multiple of 64 (conv_big.hip); -1 = shape not covered
-int conv_big_try(const void* in, const void* w, void* out, const float* bias, const float* pro_scale, const float* pro_shift,
+// tiled path for the remaining shapes with Cin a whole number of 128-byte chunks (conv_big.hip); -1 = shape not covered
+int conv_big_try(int dtype, const void* in, const void* w, void* out, const float* bias, const float* pro_scale, const float* pro_shift,
                  int epilogue, const void* aux, const float* ep_scale, const float* ep_shift, const float* ep_mean, const float* ep_rstd,
                  double* stats, int B, int Tin, int Tout, int V, int Cin, int Cout, int ntaps, int stride, int pad, int dil,
                  int transposed, hipStream_t stream);
@@ -301,9 +301,9 @@ extern "C" int stgcn_conv_rows(int dtype, const void* in, const void* w_packed, 
                                    stats, B, Tin, V, Cin, Cout, ntaps, transposed, (hipStream_t)stream);
         if (rc >= 0) return rc;
     }
-    if (dtype == STGCN_BF16 && B > 0 && Tin > 0 && Tout > 0 &&
+    if ((dtype == STGCN_BF16 || dtype == STGCN_F32) && B > 0 && Tin > 0 && Tout > 0 &&
         (epilogue == EPI_PLAIN || (epilogue == EPI_RELU_BWD && aux && ep_scale && ep_shift && ep_mean && ep_rstd))) {
-        const int rc = conv_big_try(in, w_packed, out, bias, pro_scale, pro_shift, epilogue, aux, ep_scale, ep_shift, ep_mean, ep_rstd,
+        const int rc = conv_big_try(dtype, in, w_packed, out, bias, pro_scale, pro_shift, epilogue, aux, ep_scale, ep_shift, ep_mean, ep_rstd,
                                     stats, B, Tin, Tout, V, Cin, Cout, ntaps, stride, pad, dil, transposed, (hipStream_t)stream);
         if (rc >= 0) return rc;
     }

@@ -26,7 +26,7 @@ constexpr int CW_RS = 144;
 // NPW = window pieces (16 bytes) per thread: the window of the NEXT tile is fetched into registers while the current
 // tile's MFMAs run, so its load latency is hidden.
 template <typename T, int MAXT, int NPW>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvWgradArgs a) {
+__global__ __launch_bounds__(512) void conv_wgrad_kernel(ConvWgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int ES = ET<T>::ES;
     constexpr int CT = 128 / ES;            // channels per tile side: 64 (bf16) / 32 (f32)
@@ -41,7 +41,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvWgradArgs a) {
     const int V = a.V;
     const int Rout = a.Tout * V;
     const int co0 = blockIdx.y * CT, ci0 = blockIdx.z * CT;
-    const int coh = wave & 1, cih = wave >> 1;           // bf16: wave's 32x32 quadrant
+    const int coh = wave & 1, cih = (wave >> 1) & 1;     // bf16: wave's 32x32 quadrant ...
+    const int kg = wave >> 2;                            // ... and k-step parity (8 waves = 4 quadrants x 2)
 
     f32x16 acc[MAXT];
 #pragma unroll
@@ -52,7 +53,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvWgradArgs a) {
     // tr-read lane roles (bf16): block row q, column quad p, 16-column half g1
     const int q4 = (lane & 15) >> 2, p4 = lane & 3, g1 = (lane >> 4) & 1;
 
-    // staging role: fixed 16-byte segment per thread; rows tid>>3 + 32*i
+    // staging role: fixed 16-byte segment per thread; rows tid>>3 + 64*i
     const int sseg = tid & 7, srow = tid >> 3;
     float psc[VEC], psh[VEC];
     const bool has_pro = a.pro_scale != nullptr;
@@ -64,7 +65,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvWgradArgs a) {
     const bool co_ok = co0 + sseg * VEC < a.Cout;
 
     const int ntiles = a.B * a.tiles_per_sample;
-    i32x4 dreg[4], wreg[NPW];
+    i32x4 dreg[2], wreg[NPW];
     unsigned wok = 0;                                    // bit i: wreg[i] holds a row inside [0, Tin)
     auto geom = [&](int g, int& b, int& r0, int& r1, int& tlo, int& flo, int& wrows) {
         b = g / a.tiles_per_sample;
@@ -80,8 +81,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvWgradArgs a) {
         int b, r0, r1, tlo, flo, wrows;
         geom(g, b, r0, r1, tlo, flo, wrows);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = srow + 32 * i;
+        for (int i = 0; i < 2; ++i) {
+            const int row = srow + 64 * i;
             dreg[i] = zero16();
             if (r0 + row < r1 && co_ok)
                 dreg[i] = *(const i32x4*)((const char*)a.dout + (((size_t)b * Rout + r0 + row) * a.Cout + co0 + sseg * VEC) * ES);
@@ -89,7 +90,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvWgradArgs a) {
         wok = 0;
 #pragma unroll
         for (int i = 0; i < NPW; ++i) {
-            const int row = srow + 32 * i;
+            const int row = srow + 64 * i;
             wreg[i] = zero16();
             if (row < wrows) {
                 const int fr = row / V;
@@ -103,10 +104,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvWgradArgs a) {
     };
     auto commit = [&](int wrows) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) *(i32x4*)(dtile + (srow + 32 * i) * CW_RS + sseg * 16) = dreg[i];
+        for (int i = 0; i < 2; ++i) *(i32x4*)(dtile + (srow + 64 * i) * CW_RS + sseg * 16) = dreg[i];
 #pragma unroll
         for (int i = 0; i < NPW; ++i) {
-            const int row = srow + 32 * i;
+            const int row = srow + 64 * i;
             if (row < wrows) {
                 i32x4 v = wreg[i];
                 if (has_pro && ((wok >> i) & 1u)) {
@@ -137,11 +138,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvWgradArgs a) {
         if (g + a.nseg < ntiles) fetch(g + a.nseg);      // in flight during this tile's MFMAs
 
         if constexpr (BF) {
-            // wave (coh, cih): all 128 rows, 8 k-steps of 16 rows
+            // wave (coh, cih, kg): the k-steps (16 rows each) of parity kg among the 8 of the tile
             const int acol = (coh * 32 + 16 * g1 + 4 * p4) * 2;
             const int bcol = (cih * 32 + 16 * g1 + 4 * p4) * 2;
 #pragma unroll 2
-            for (int s = 0; s < 8; ++s) {
+            for (int sj = 0; sj < 4; ++sj) {
+                const int s = 2 * sj + kg;
                 const int rowa = 16 * s + 8 * h + q4;       // this lane's address row, first read
                 const int rowb = rowa + 4;                  // second read
                 const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(dtile + rowa * CW_RS + acol));
@@ -160,10 +162,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvWgradArgs a) {
                 }
             }
         } else {
-            // wave owns rows [32*wave, 32*wave+32); 16 steps of 2 rows
+            // wave owns rows [16*wave, 16*wave+16) of the 32 x 32 (co, ci) tile's contraction; 8 steps of 2 rows
 #pragma unroll 4
-            for (int s = 0; s < 16; ++s) {
-                const int row = 32 * wave + 2 * s + h;
+            for (int s = 0; s < 8; ++s) {
+                const int row = 16 * wave + 2 * s + h;
                 const float av = *(const float*)(dtile + row * CW_RS + l31 * 4);
                 const int wo = rb[row] + l31 * 4;
 #pragma unroll
@@ -177,18 +179,39 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvWgradArgs a) {
         }
     }
 
-    // partial slab: acc[t] row = co (acc_row), col = ci (lane)
-    const int part = BF ? blockIdx.x : blockIdx.x * 4 + wave;
-    const int cob = co0 + (BF ? coh * 32 : 0);
-    const int ci = ci0 + (BF ? cih * 32 : 0) + l31;
+    // Fold the waves that hold partial sums of the same tile through LDS, one tap at a time: f32 -- all 8 waves;
+    // bf16 -- the two k-step parities of each quadrant.  One partial per workgroup goes to the slab.
+    float* red = (float*)smem;                            // [8 waves][16][64] floats = 32 KiB
+    const int part = blockIdx.x;
 #pragma unroll
     for (int t = 0; t < MAXT; ++t) {
         if (t < a.ntaps) {
+            lds_barrier();
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int co = cob + acc_row(r, h);
-                if (co < a.Cout && ci < a.Cin)
-                    a.slab[(((size_t)part * a.ntaps + t) * a.Cout + co) * a.Cin + ci] = acc[t][r];
+            for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[t][r];
+            lds_barrier();
+            if constexpr (BF) {
+                // 4 quadrants x 1024 values: 8 per thread
+                for (int e = tid; e < 4 * 1024; e += 512) {
+                    const int quad = e >> 10, idx = e & 1023;
+                    const float v = red[quad * 1024 + idx] + red[(quad + 4) * 1024 + idx];
+                    const int r = idx >> 6, ln = idx & 63;
+                    const int co = co0 + (quad & 1) * 32 + acc_row(r, ln >> 5);
+                    const int ci = ci0 + (quad >> 1) * 32 + (ln & 31);
+                    if (co < a.Cout && ci < a.Cin)
+                        a.slab[(((size_t)part * a.ntaps + t) * a.Cout + co) * a.Cin + ci] = v;
+                }
+            } else {
+                for (int idx = tid; idx < 1024; idx += 512) {
+                    float v = 0.f;
+#pragma unroll
+                    for (int w = 0; w < 8; ++w) v += red[w * 1024 + idx];
+                    const int r = idx >> 6, ln = idx & 63;
+                    const int co = co0 + acc_row(r, ln >> 5);
+                    const int ci = ci0 + (ln & 31);
+                    if (co < a.Cout && ci < a.Cin)
+                        a.slab[(((size_t)part * a.ntaps + t) * a.Cout + co) * a.Cin + ci] = v;
+                }
             }
         }
     }
@@ -470,24 +493,24 @@ static int conv_wgrad_run(ConvWgradArgs& a, float* dW, size_t ws_bytes, hipStrea
     int nseg = 1024 / (ncot * ncit);
     if (nseg < 1) nseg = 1;
     if (nseg > ntiles) nseg = ntiles;
-    const int wave_parts = ET<T>::IS_BF16 ? 1 : 4;
+    const int wave_parts = 1;                             // the waves of a workgroup are folded in LDS
     const size_t per_part = (size_t)a.ntaps * a.Cout * a.Cin * sizeof(float);
     while (nseg > 1 && (size_t)nseg * wave_parts * per_part > ws_bytes) nseg /= 2;
     if ((size_t)nseg * wave_parts * per_part > ws_bytes) return STGCN_ERR_WORKSPACE;
     a.nseg = nseg;
     dim3 grid((unsigned)nseg, (unsigned)ncot, (unsigned)ncit);
     int rc;
-    const int npw = ceil_div_i(a.win_rows_max, 32);      // window pieces per thread (32 rows per staging pass)
-    if (npw > 24) return STGCN_ERR_ARG;
+    const int npw = ceil_div_i(a.win_rows_max, 64);      // window pieces per thread (64 rows per staging pass)
+    if (npw > 12) return STGCN_ERR_ARG;
 #define CW_LAUNCH(MT_, NP_) do { \
         auto kern = conv_wgrad_kernel<T, MT_, NP_>; \
         static bool set_ = false; \
         if (!set_) { if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return STGCN_ERR_LAUNCH; set_ = true; } \
-        hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, a); } while (0)
+        hipLaunchKernelGGL(kern, grid, dim3(512), lds, stream, a); } while (0)
     if (a.ntaps == 1) {
-        if (npw <= 12) CW_LAUNCH(1, 12); else CW_LAUNCH(1, 24);
+        if (npw <= 6) CW_LAUNCH(1, 6); else CW_LAUNCH(1, 12);
     } else {
-        if (npw <= 12) CW_LAUNCH(9, 12); else if (npw <= 17) CW_LAUNCH(9, 17); else CW_LAUNCH(9, 24);
+        if (npw <= 6) CW_LAUNCH(9, 6); else if (npw <= 9) CW_LAUNCH(9, 9); else CW_LAUNCH(9, 12);
     }
 #undef CW_LAUNCH
     rc = hipGetLastError() == hipSuccess ? STGCN_OK : STGCN_ERR_LAUNCH;

@@ -25,7 +25,8 @@ constexpr int CW_RS = 144;
 
 // NPW = window pieces (16 bytes) per thread: the window of the NEXT tile is fetched into registers while the current
 // tile's MFMAs run, so its load latency is hidden.
-template <typename T, int MAXT, int NPW>
+// EXACT: ntaps == MAXT, so the tap loops carry no run-time tests (the LDS reads of a k-step are then issued together).
+template <typename T, int MAXT, int NPW, bool EXACT>
 __global__ __launch_bounds__(512) void conv_wgrad_kernel(ConvWgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int ES = ET<T>::ES;
@@ -152,7 +153,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(ConvWgradArgs a) {
                 const int wa = rb[rowa] + bcol, wb = rb[rowb] + bcol;
 #pragma unroll
                 for (int t = 0; t < MAXT; ++t) {
-                    if (t < a.ntaps) {
+                    if (EXACT || t < a.ntaps) {
                         const int sh = t * a.dil * V * CW_RS;
                         const s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(win + wa + sh));
                         const s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(win + wb + sh));
@@ -170,7 +171,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(ConvWgradArgs a) {
                 const int wo = rb[row] + l31 * 4;
 #pragma unroll
                 for (int t = 0; t < MAXT; ++t) {
-                    if (t < a.ntaps) {
+                    if (EXACT || t < a.ntaps) {
                         const float bv = *(const float*)(win + wo + t * a.dil * V * CW_RS);
                         acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
                     }
@@ -185,7 +186,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(ConvWgradArgs a) {
     const int part = blockIdx.x;
 #pragma unroll
     for (int t = 0; t < MAXT; ++t) {
-        if (t < a.ntaps) {
+        if (EXACT || t < a.ntaps) {
             lds_barrier();
 #pragma unroll
             for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[t][r];
@@ -249,7 +250,8 @@ struct ConvWgradRingArgs {
     int tile_rows;       // output rows one tile advances by (256, or OT*V for stride 2)
 };
 
-template <int STRIDE>
+// NT = number of taps (compile-time: the tap loops carry no run-time tests, so a k-step's LDS reads issue together)
+template <int STRIDE, int NT>
 __global__ __launch_bounds__(512) void conv_wgrad_ring_kernel(ConvWgradRingArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int RS = 144;
@@ -283,9 +285,9 @@ __global__ __launch_bounds__(512) void conv_wgrad_ring_kernel(ConvWgradRingArgs 
         return j + q * V;
     };
 
-    f32x16 acc[9];
+    f32x16 acc[NT];
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
@@ -370,29 +372,44 @@ __global__ __launch_bounds__(512) void conv_wgrad_ring_kernel(ConvWgradRingArgs 
             lds_barrier();                              // ring and dt[cur] visible
             if (more) fetch_do(p0 + tile_rows);
             const char* dcur = dt + (size_t)cur * DROWS * RS;
-            auto kstep = [&](int s, int ro0, int ro1) {
-                const int rowa = 16 * s + 8 * h + q4;
-                const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(dcur + rowa * RS + acol));
-                const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(dcur + (rowa + 4) * RS + acol));
-                const s16x8 af = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
-#pragma unroll
-                for (int t = 0; t < 9; ++t) {
-                    if (t < ntaps) {
-                        const int r0 = (first + ro0 + t * V) & 511, r1 = (first + ro1 + t * V) & 511;
-                        const s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(ring + r0 * RS + bcol));
-                        const s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(ring + r1 * RS + bcol));
-                        const s16x8 bfv = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
-                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfv, acc[t], 0, 0, 0);
-                    }
-                }
+            // Fragment reads run one MFMA ahead: the tap t+1 operand (or the next k-step's dout fragment and
+            // tap-0 operand) is requested before the tap t MFMA issues, so the LDS latency hides under the MFMA pipe.
+            auto tr = [&](const char* p) {
+                return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
             };
+            auto lda = [&](int s) -> s16x8 {
+                const int rowa = 16 * s + 8 * h + q4;
+                const s16x4 a0 = tr(dcur + rowa * RS + acol), a1 = tr(dcur + (rowa + 4) * RS + acol);
+                return s16x8{a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+            };
+            auto ldb = [&](int ro0, int ro1, int t) -> s16x8 {
+                const int r0 = (first + ro0 + t * V) & 511, r1 = (first + ro1 + t * V) & 511;
+                const s16x4 b0 = tr(ring + r0 * RS + bcol), b1 = tr(ring + r1 * RS + bcol);
+                return s16x8{b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+            };
+            int ro0 = in_off(16 * kg + 8 * h + q4), ro1 = in_off(16 * kg + 8 * h + q4 + 4);
+            s16x8 af = lda(kg), bc = ldb(ro0, ro1, 0);
 #pragma unroll 1
             for (int hs = 0; hs < 2; ++hs) {
-#pragma unroll 2
+#pragma unroll 1
                 for (int sj = 0; sj < KW / 2; ++sj) {
-                    const int s = 2 * (hs * (KW / 2) + sj) + kg;
-                    const int j = 16 * s + 8 * h + q4;
-                    kstep(s, in_off(j), in_off(j + 4));
+                    // the step after the tile's last wraps to the first: its reads are valid and unused
+                    const int sn = 2 * ((hs * (KW / 2) + sj + 1) & (KW - 1)) + kg;
+                    const int jn = 16 * sn + 8 * h + q4;
+                    const int rn0 = in_off(jn), rn1 = in_off(jn + 4);
+                    s16x8 afn = af;
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        s16x8 bn;
+                        if (t + 1 < NT) bn = ldb(ro0, ro1, t + 1);
+                        else { afn = lda(sn); bn = ldb(rn0, rn1, 0); }
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bc, acc[t], 0, 0, 0);
+                        if (t + 1 < NT) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                        else __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        bc = bn;
+                    }
+                    af = afn; ro0 = rn0; ro1 = rn1;
                 }
                 if (hs == 0 && more) {
                     commit_do(cur ^ 1);                   // last read a tile ago: every wave has passed a barrier since
@@ -408,8 +425,8 @@ __global__ __launch_bounds__(512) void conv_wgrad_ring_kernel(ConvWgradRingArgs 
     // fold the odd-k-step waves into their even partners through LDS, one tap at a time
     float* red = (float*)smem;                            // [4][16][64] floats
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
-        if (t < ntaps) {
+    for (int t = 0; t < NT; ++t) {
+        {
             lds_barrier();
             if (kg == 1) {
 #pragma unroll
@@ -427,8 +444,8 @@ __global__ __launch_bounds__(512) void conv_wgrad_ring_kernel(ConvWgradRingArgs 
     const int cob = co0 + coh * 32;
     const int ci = ci0 + cih * 32 + l31;
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
-        if (t < ntaps) {
+    for (int t = 0; t < NT; ++t) {
+        {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = cob + acc_row(r, h);
@@ -443,7 +460,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_ring_kernel(ConvWgradRingArgs 
 static int conv_wgrad_ring_try(const void* in, const void* dout, float* dW, const float* pro_scale, const float* pro_shift,
                                int B, int Tin, int Tout, int V, int Cin, int Cout, int ntaps, int stride,
                                void* ws, size_t ws_bytes, hipStream_t stream) {
-    if (Cin % 64 != 0 || Cout % 8 != 0 || V > 32 || V < 1 || ntaps > 9 || (ntaps & 1) == 0) return -1;
+    if (Cin % 64 != 0 || Cout % 8 != 0 || V > 32 || V < 1 || (ntaps != 9 && ntaps != 1)) return -1;
     if (stride != 1 && stride != 2) return -1;
     ConvWgradRingArgs a;
     a.in = in; a.dout = dout; a.slab = (float*)ws; a.pro_scale = pro_scale; a.pro_shift = pro_shift;
@@ -466,12 +483,18 @@ static int conv_wgrad_ring_try(const void* in, const void* dout, float* dW, cons
     a.tiles_per_seg = tps; a.segs_per_sample = segs; a.nruns = B * segs;
     if (nwg > a.nruns) nwg = a.nruns;
     const size_t lds = 512 * 144 + 2 * (stride == 1 ? 256 : 128) * 144;
-    const void* fn = stride == 1 ? (const void*)conv_wgrad_ring_kernel<1> : (const void*)conv_wgrad_ring_kernel<2>;
-    static bool set[2] = {false, false};
-    if (!set[stride - 1]) { if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return STGCN_ERR_LAUNCH; set[stride - 1] = true; }
+    const int variant = (stride - 1) * 2 + (ntaps == 9 ? 1 : 0);
+    const void* fns[4] = {(const void*)conv_wgrad_ring_kernel<1, 1>, (const void*)conv_wgrad_ring_kernel<1, 9>,
+                          (const void*)conv_wgrad_ring_kernel<2, 1>, (const void*)conv_wgrad_ring_kernel<2, 9>};
+    static bool set[4] = {false, false, false, false};
+    if (!set[variant]) { if (hipFuncSetAttribute(fns[variant], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return STGCN_ERR_LAUNCH; set[variant] = true; }
     const dim3 grid((unsigned)nwg, (unsigned)ncot, (unsigned)ncit);
-    if (stride == 1) hipLaunchKernelGGL(conv_wgrad_ring_kernel<1>, grid, dim3(512), lds, stream, a);
-    else hipLaunchKernelGGL(conv_wgrad_ring_kernel<2>, grid, dim3(512), lds, stream, a);
+    switch (variant) {
+        case 0: hipLaunchKernelGGL((conv_wgrad_ring_kernel<1, 1>), grid, dim3(512), lds, stream, a); break;
+        case 1: hipLaunchKernelGGL((conv_wgrad_ring_kernel<1, 9>), grid, dim3(512), lds, stream, a); break;
+        case 2: hipLaunchKernelGGL((conv_wgrad_ring_kernel<2, 1>), grid, dim3(512), lds, stream, a); break;
+        default: hipLaunchKernelGGL((conv_wgrad_ring_kernel<2, 9>), grid, dim3(512), lds, stream, a); break;
+    }
     if (hipGetLastError() != hipSuccess) return STGCN_ERR_LAUNCH;
     const size_t n = (size_t)ntaps * Cout * Cin;
     const int left = fold_parts(a.slab, nwg, n, stream);
@@ -502,15 +525,17 @@ static int conv_wgrad_run(ConvWgradArgs& a, float* dW, size_t ws_bytes, hipStrea
     int rc;
     const int npw = ceil_div_i(a.win_rows_max, 64);      // window pieces per thread (64 rows per staging pass)
     if (npw > 12) return STGCN_ERR_ARG;
-#define CW_LAUNCH(MT_, NP_) do { \
-        auto kern = conv_wgrad_kernel<T, MT_, NP_>; \
+#define CW_LAUNCH(MT_, NP_, EX_) do { \
+        auto kern = conv_wgrad_kernel<T, MT_, NP_, EX_>; \
         static bool set_ = false; \
         if (!set_) { if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return STGCN_ERR_LAUNCH; set_ = true; } \
         hipLaunchKernelGGL(kern, grid, dim3(512), lds, stream, a); } while (0)
     if (a.ntaps == 1) {
-        if (npw <= 6) CW_LAUNCH(1, 6); else CW_LAUNCH(1, 12);
+        if (npw <= 6) CW_LAUNCH(1, 6, true); else CW_LAUNCH(1, 12, true);
+    } else if (a.ntaps == 9) {
+        if (npw <= 6) CW_LAUNCH(9, 6, true); else if (npw <= 9) CW_LAUNCH(9, 9, true); else CW_LAUNCH(9, 12, true);
     } else {
-        if (npw <= 6) CW_LAUNCH(9, 6); else if (npw <= 9) CW_LAUNCH(9, 9); else CW_LAUNCH(9, 12);
+        CW_LAUNCH(9, 12, false);
     }
 #undef CW_LAUNCH
     rc = hipGetLastError() == hipSuccess ? STGCN_OK : STGCN_ERR_LAUNCH;

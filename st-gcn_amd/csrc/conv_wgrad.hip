@@ -254,13 +254,19 @@ struct ConvWgradRingArgs {
 template <int STRIDE, int NT>
 __global__ __launch_bounds__(512) void conv_wgrad_ring_kernel(ConvWgradRingArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int RS = 144;
+    // Stride 1: LDS rows are 128 bytes, unpadded; the 64-byte half of a row is flipped on rows with bit 1 set, so
+    // the four consecutive rows one transposed read touches per 32-lane half land on four different quarters of the
+    // bank row (conflict-free), and each lane keeps one ring address per tap that it advances by 32 rows per k-step
+    // pair with a 16-bit wrap (the ring is 64 KiB at the start of the LDS allocation).  Stride 2 computes its row
+    // offsets per read and keeps rows padded to 144 bytes, unswizzled.
+    constexpr int RS = STRIDE == 1 ? 128 : 144;
     constexpr int KS = STRIDE == 1 ? 16 : 8;              // k-steps (16 output rows each) per tile
     constexpr int DROWS = KS * 16;                        // dout rows per tile buffer
     constexpr int DPASS = DROWS / 64;                     // staging passes for a dout tile (64 rows per pass)
     constexpr int KW = KS / 2;                            // k-steps per wave: waves 0-3 take the even ones, 4-7 the odd
-    char* ring = smem;                                   // [512][RS]
-    char* dt = smem + 512 * RS;                          // 2 x [DROWS][RS]
+    char* ring = smem;                                   // [512 + 4][RS]: slots 512..515 mirror slots 0..3
+    char* dt = smem + 516 * RS;                          // 2 x [DROWS][RS]
+    auto swz = [](int row) -> int { return STRIDE == 1 ? (row & 2) << 5 : 0; };
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5;
     const int V = a.V, Rin = a.Rin, Rout = a.Rout, Cin = a.Cin, Cout = a.Cout, ntaps = a.ntaps;
@@ -268,7 +274,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_ring_kernel(ConvWgradRingArgs 
     const int co0 = blockIdx.y * 64, ci0 = blockIdx.z * 64;
     const int coh = wave & 1, cih = (wave >> 1) & 1, kg = wave >> 2;
     const int q4 = (lane & 15) >> 2, p4 = lane & 3, g1 = (lane >> 4) & 1;
-    const int acol = (coh * 32 + 16 * g1 + 4 * p4) * 2;
+    const int acol = ((coh * 32 + 16 * g1 + 4 * p4) * 2) ^ swz(q4);   // dout rows of a read are q4 (+4) mod 8
     const int bcol = (cih * 32 + 16 * g1 + 4 * p4) * 2;
     const int tile_rows = a.tile_rows;
     const int in_adv = STRIDE * tile_rows;                // input rows one tile advances by
@@ -334,7 +340,10 @@ __global__ __launch_bounds__(512) void conv_wgrad_ring_kernel(ConvWgradRingArgs 
                 if (rel < nrows) {
                     i32x4 v = pf[i];
                     if (p >= 0 && p < Rin) v = transform(v);
-                    *(i32x4*)(ring + (size_t)(p & 511) * RS + sseg * 16) = v;
+                    const int slot = p & 511;
+                    const int off = slot * RS + ((sseg * 16) ^ swz(slot));
+                    *(i32x4*)(ring + off) = v;
+                    if (slot < 4) *(i32x4*)(ring + off + 512 * RS) = v;
                 }
             }
         };
@@ -350,7 +359,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_ring_kernel(ConvWgradRingArgs 
         auto commit_do = [&](int buf) {
 #pragma unroll
             for (int i = 0; i < DPASS; ++i)
-                *(i32x4*)(dt + (size_t)buf * DROWS * RS + (srow + 64 * i) * RS + sseg * 16) = pf[i];
+                *(i32x4*)(dt + (size_t)buf * DROWS * RS + (srow + 64 * i) * RS + ((sseg * 16) ^ swz(srow))) = pf[i];
         };
 
         int p0 = tile_beg * tile_rows;                    // first output row of the tile
@@ -365,6 +374,15 @@ __global__ __launch_bounds__(512) void conv_wgrad_ring_kernel(ConvWgradRingArgs 
             commit_do(0);
         }
         int cur = 0;
+        // stride 1: ring byte offset of this lane's first operand row of the coming k-step, per tap
+        uint16_t badr[NT];
+        if constexpr (STRIDE == 1) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int slot = (p0 - half * V + 16 * kg + 8 * h + q4 + t * V) & 511;
+                badr[t] = (uint16_t)(slot * RS + (bcol ^ swz(slot)));
+            }
+        }
         for (int tile = tile_beg; tile < tile_end; ++tile, p0 += tile_rows) {
             const bool more = tile + 1 < tile_end;
             const int first = STRIDE * p0 - half * V;     // first input row of this tile's span
@@ -382,18 +400,31 @@ __global__ __launch_bounds__(512) void conv_wgrad_ring_kernel(ConvWgradRingArgs 
                 const s16x4 a0 = tr(dcur + rowa * RS + acol), a1 = tr(dcur + (rowa + 4) * RS + acol);
                 return s16x8{a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
             };
-            auto ldb = [&](int ro0, int ro1, int t) -> s16x8 {
-                const int r0 = (first + ro0 + t * V) & 511, r1 = (first + ro1 + t * V) & 511;
-                const s16x4 b0 = tr(ring + r0 * RS + bcol), b1 = tr(ring + r1 * RS + bcol);
+            // adv: bytes the lane's tap address moves on after the read (0 for the unused read after the last k-step)
+            auto ldb = [&](int ro0, int ro1, int t, int adv) -> s16x8 {
+                const char* p0;
+                const char* p1;
+                if constexpr (STRIDE == 1) {
+                    p0 = ring + (uint32_t)badr[t];
+                    p1 = p0 + 4 * RS;                       // rows +4: the mirror slots cover the wrap
+                    badr[t] = (uint16_t)(badr[t] + (uint16_t)adv);
+                } else {
+                    const int r0 = (first + ro0 + t * V) & 511, r1 = (first + ro1 + t * V) & 511;
+                    p0 = ring + r0 * RS + bcol; p1 = ring + r1 * RS + bcol;
+                }
+                const s16x4 b0 = tr(p0), b1 = tr(p1);
                 return s16x8{b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
             };
+            constexpr int ADV = 32 * RS;                  // a wave's next k-step is 32 rows on
+            constexpr int STEP_UNROLL = NT == 1 ? KW / 2 : 1;
             int ro0 = in_off(16 * kg + 8 * h + q4), ro1 = in_off(16 * kg + 8 * h + q4 + 4);
-            s16x8 af = lda(kg), bc = ldb(ro0, ro1, 0);
+            s16x8 af = lda(kg), bc = ldb(ro0, ro1, 0, ADV);
 #pragma unroll 1
             for (int hs = 0; hs < 2; ++hs) {
-#pragma unroll 1
+#pragma unroll STEP_UNROLL
                 for (int sj = 0; sj < KW / 2; ++sj) {
                     // the step after the tile's last wraps to the first: its reads are valid and unused
+                    const int adv0 = (hs == 1 && sj == KW / 2 - 1) ? 0 : ADV;
                     const int sn = 2 * ((hs * (KW / 2) + sj + 1) & (KW - 1)) + kg;
                     const int jn = 16 * sn + 8 * h + q4;
                     const int rn0 = in_off(jn), rn1 = in_off(jn + 4);
@@ -401,8 +432,8 @@ __global__ __launch_bounds__(512) void conv_wgrad_ring_kernel(ConvWgradRingArgs 
 #pragma unroll
                     for (int t = 0; t < NT; ++t) {
                         s16x8 bn;
-                        if (t + 1 < NT) bn = ldb(ro0, ro1, t + 1);
-                        else { afn = lda(sn); bn = ldb(rn0, rn1, 0); }
+                        if (t + 1 < NT) bn = ldb(ro0, ro1, t + 1, ADV);
+                        else { afn = lda(sn); bn = ldb(rn0, rn1, 0, adv0); }
                         acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bc, acc[t], 0, 0, 0);
                         if (t + 1 < NT) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
                         else __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
@@ -482,7 +513,7 @@ static int conv_wgrad_ring_try(const void* in, const void* dout, float* dW, cons
     segs = ceil_div_i(ntiles, tps);
     a.tiles_per_seg = tps; a.segs_per_sample = segs; a.nruns = B * segs;
     if (nwg > a.nruns) nwg = a.nruns;
-    const size_t lds = 512 * 144 + 2 * (stride == 1 ? 256 : 128) * 144;
+    const size_t lds = stride == 1 ? 516 * 128 + 2 * 256 * 128 : 516 * 144 + 2 * 128 * 144;
     const int variant = (stride - 1) * 2 + (ntaps == 9 ? 1 : 0);
     const void* fns[4] = {(const void*)conv_wgrad_ring_kernel<1, 1>, (const void*)conv_wgrad_ring_kernel<1, 9>,
                           (const void*)conv_wgrad_ring_kernel<2, 1>, (const void*)conv_wgrad_ring_kernel<2, 9>};

@@ -822,8 +822,10 @@ __global__ __launch_bounds__(768) void gcn_wgrad_wide_kernel(GcnWgradWideArgs a)
     const int l31 = lane & 31, h = lane >> 5;
     const int V = a.V, K = a.K, Cin = a.Cin, Cout = a.Cout, FB = a.FB;
     constexpr int nci = NCI;
-    constexpr int DRS = 64 * 2 + 16;
-    const int XRS = Cin * 2 + 16;
+    // row strides are 64 bytes past a multiple of 256, so the four consecutive rows a transposed read touches per
+    // 32-lane half fall on four different quarters of the 64 banks (conflict-free)
+    constexpr int DRS = 64 * 2 + 64;
+    const int XRS = (Cin * 2 + 127) / 128 * 128 + 64;
     char* tab = smem;                                     // [K][2][64] x 16 B
     char* dimg = smem + (size_t)K * 2 * 64 * 16;          // [FB][32][DRS]
     char* ximg = dimg + (size_t)FB * 32 * DRS;            // [FB][32][XRS] (+32 B slack for partial ci tiles)
@@ -989,7 +991,7 @@ static int gcn_wgrad_wide_try(const void* x, const void* dy, const float* adj, f
     a.cit = cit; a.nci = cit >= 2 ? cit / 2 : 1;
     const int nw = K * 2 * (cit / a.nci);
     const int nt = nw * 64;
-    const size_t per_frame = (size_t)32 * (144 + Cin * 2 + 16);
+    const size_t per_frame = (size_t)32 * (192 + (Cin * 2 + 127) / 128 * 128 + 64);
     int fb = 8;
     while (fb > 1 && ((size_t)fb * per_frame > 120 * 1024 || ceil_div_i(fb * V * 8, nt) > GW_MAXD || ceil_div_i(fb * V * (Cin / 8), nt) > GW_MAXX)) --fb;
     if (ceil_div_i(fb * V * 8, nt) > GW_MAXD || ceil_div_i(fb * V * (Cin / 8), nt) > GW_MAXX) return -1;

@@ -239,25 +239,28 @@ __global__ __launch_bounds__(WR * WC * 64) void conv_big_kernel(ConvBigArgs a) {
                     lds_barrier();                         // weight tile of this step (and a new window) visible
                     const int wnext = wcur == 2 ? 0 : wcur + 1;
                     const int wstore = wnext == 2 ? 0 : wnext + 1;
-                    store_w(wstore);                       // tile of step +2; its buffer was read during step -1
-                    load_w_next();                         // tile of step +3
                     if constexpr (true) {
                         if (tapi == 0) {                   // first step on a new window: nothing was prefetched
                             a_offsets(0, aoff);
                             load_frag(fa, aoff, wcur, 0);
                         }
                         const bool chain = tapi + 1 < ntaps;   // the next step reads the same window
-                        if (chain) a_offsets(tapi + 1, aoff_n);
-                        // 4 k-steps; the fragments of the next one (or of the next step's first) ride under the MFMAs
+                        // 4 k-steps; the fragments of the next one (or of the next step's first) ride under the MFMAs.
+                        // The step's bookkeeping (publishing the weight tile of step +2, fetching that of step +3,
+                        // the next tap's row offsets) sits behind the first MFMAs, not in front of them: both waves
+                        // of a SIMD leave the barrier together, and whatever precedes the first MFMA idles the pipe.
                         __builtin_amdgcn_sched_barrier(0);
                         load_frag(fb, aoff, wcur, 1);
                         mma_frag(fa);
                         CB_INTERLEAVE(MT + NT, MT * NT)
                         __builtin_amdgcn_sched_barrier(0);
+                        store_w(wstore);                   // tile of step +2; its buffer was read during step -1
                         load_frag(fa, aoff, wcur, 2);
                         mma_frag(fb);
                         CB_INTERLEAVE(MT + NT, MT * NT)
                         __builtin_amdgcn_sched_barrier(0);
+                        load_w_next();                     // tile of step +3
+                        if (chain) a_offsets(tapi + 1, aoff_n);
                         load_frag(fb, aoff, wcur, 3);
                         mma_frag(fa);
                         CB_INTERLEAVE(MT + NT, MT * NT)

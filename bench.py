@@ -57,8 +57,8 @@ def kernel_work(key):
         rows, C, has_r = key[3], key[4], key[5]
         p = key[2]
         want_g = len(key) > 6 and key[6]
-        # read: dout, o (+ r) and the ReLU bit mask (1/16 of a tensor); the apply pass also writes dO (+ dR) (+ g)
-        n = (3 if has_r else 2) + 1.0 / 16 + (0 if p == 0 else (2 if has_r else 1) + (1 if want_g else 0))
+        # read: dout, o (+ r) and the ReLU/dropout bit mask (1/8 of a tensor); the apply pass also writes dO (+ dR) (+ g)
+        n = (3 if has_r else 2) + 1.0 / 8 + (0 if p == 0 else (2 if has_r else 1) + (1 if want_g else 0))
         return 0.0, rows * C * es * n, "hbm"
     if name == "stgcn_bn_bwd_apply":
         _, dt, rows, C = key

@@ -89,8 +89,9 @@ int stgcn_bn_finalize(const double* stats, double count, const float* gamma, con
 int stgcn_stats_to_grads(const double* stats, float* dgamma, float* dbeta, int C, void* stream);
 
 /* out = relu((scale2*o + shift2) * keep/(1-p) + res'), res' = res_scale*res + res_shift | res | 0.
- * relu_mask (optional, rows*C/8 bytes for bf16, rows*C/4 for f32): one byte per 16-byte piece of out, bit j set
- * when element j of the piece is positive -- the backward then reads 1/16 of the bytes of out.
+ * relu_mask (optional, 2 bytes per 16-byte piece of out: rows*C/4 bytes for bf16, rows*C/2 for f32): bit j set when
+ * element j of the piece is positive, bit 8+j when dropout kept it -- the backward then reads 1/8 of the bytes of
+ * out and evaluates no dropout hash.
  * Replaces: BatchNorm2d apply + Dropout + residual add + ReLU (net/st_gcn.py:169-170, 193-197). */
 int stgcn_block_out_fwd(int dtype, const void* o, const void* res, void* out, void* relu_mask,
                         const float* scale2, const float* shift2, const float* res_scale, const float* res_shift,
@@ -99,8 +100,8 @@ int stgcn_block_out_fwd(int dtype, const void* o, const void* res, void* out, vo
 /* Backward of the stage above.  pass 0: per-channel sums (stats2, statsr).  pass 1: dO (BatchNorm backward of the
  * main branch), dR (same for a conv residual), g (= masked incoming gradient, for an identity residual), and the
  * bias gradients of the two convolutions (dbias_*).  The incoming gradient is dout and/or dpool (float32 [B][C],
- * constant over (t,v): the gradient of the global average pool).  The ReLU decisions come from relu_mask when
- * given (then out may be null), else from out.
+ * constant over (t,v): the gradient of the global average pool).  The ReLU and dropout decisions come from relu_mask when
+ * given (then out may be null), else from out and the dropout hash.
  * Replaces: autograd of net/st_gcn.py:169-170, 193-197 (and of F.avg_pool2d, st_gcn.py:85, for dpool). */
 int stgcn_block_out_bwd(int dtype, int pass, const void* dout, const float* dpool, size_t rows_per_sample,
                         const void* out, const void* relu_mask, const void* o, const void* r,

@@ -146,15 +146,18 @@ def det_uniform(shape, tag, lo=-1.0, hi=1.0):
 
 
 def dropout_keep_mask(numel, seed, p):
-    """Keep-mask of the HIP dropout: element i is kept iff hash32(i, seed) >= p*2^32.
+    """Keep-mask of the HIP dropout: one 32-bit hash serves elements 2q and 2q+1 (low / high 16 bits); an element is
+    kept iff its 16 bits are >= round(p * 65536).
 
-    Same integer hash as csrc (stgcn_common.h: drop_hash).  Returns float64 {0,1}.
+    Same integer hash as csrc (stgcn_common.h: drop_hash, drop_keep_bits).  Returns float64 {0,1}.
     """
     if p <= 0.0:
         return np.ones(numel)
+    idx = np.arange(numel, dtype=np.uint64)
+    pair = idx >> np.uint64(1)
     with np.errstate(over="ignore"):
-        x = (np.arange(numel, dtype=np.uint64) & np.uint64(0xFFFFFFFF)).astype(np.uint32)
-        hi = (np.arange(numel, dtype=np.uint64) >> np.uint64(32)).astype(np.uint32)
+        x = (pair & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+        hi = (pair >> np.uint64(32)).astype(np.uint32)
         x = x ^ np.uint32(seed & 0xFFFFFFFF)
         x = x + hi * np.uint32(0x9E3779B9)
         x ^= x >> np.uint32(16)
@@ -162,8 +165,9 @@ def dropout_keep_mask(numel, seed, p):
         x ^= x >> np.uint32(15)
         x *= np.uint32(0x846CA68B)
         x ^= x >> np.uint32(16)
-    thr = np.uint32(min(int(p * 4294967296.0), 0xFFFFFFFF))
-    return (x >= thr).astype(np.float64)
+    half = np.where((idx & np.uint64(1)) == 0, x & np.uint32(0xFFFF), x >> np.uint32(16))
+    thr = max(1, min(int(p * 65536.0 + 0.5), 65535))
+    return (half >= np.uint32(thr)).astype(np.float64)
 
 
 # --------------------------------------------------------------------------

@@ -6,11 +6,12 @@
 // registers -> LDS -> one double atomic per channel per workgroup).
 #include "stgcn_common.h"
 
-template <typename T> struct RowMap {
+// NT = threads per workgroup
+template <typename T, int NT = 256> struct RowMap {
     int cvs, rpi, cv, rl; bool active;
     __device__ RowMap(int C) {
         cvs = C / ET<T>::VEC;
-        rpi = 256 / cvs; if (rpi < 1) rpi = 1;
+        rpi = NT / cvs; if (rpi < 1) rpi = 1;
         cv = threadIdx.x % cvs; rl = threadIdx.x / cvs;
         active = rl < rpi && (int)threadIdx.x < cvs * rpi;
     }
@@ -34,6 +35,42 @@ __device__ __forceinline__ void block_channel_reduce(float (*sums)[ET<T>::VEC], 
         float tot = 0.f;
         for (int r = 0; r < m.rpi; ++r) tot += red[((r * m.cvs + cv) * NS + s) * VEC + j];
         atomicAdd(&dst[s][c], (double)tot);
+    }
+}
+
+// The same for workgroups of NT > 256 threads whose rows hold at most 64 channel vectors (cvs <= 64, a power of
+// two): lanes of a wave that own the same channels are folded with shuffles first, then the NT/64 waves through
+// LDS, one sum at a time.  Big workgroups keep the number of workgroups -- and with it the number of double
+// atomics that pile up on the same few cache lines at the end of the kernel -- small.
+template <typename T, int NS, int NT>
+__device__ __forceinline__ void wide_channel_reduce(float (*sums)[ET<T>::VEC], const RowMap<T, NT>& m, int C, double* const* dst) {
+    constexpr int VEC = ET<T>::VEC;
+    constexpr int NW = NT / 64;
+    __shared__ float red[NW * 64 * VEC];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        float v[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            v[j] = m.active ? sums[s][j] : 0.f;
+            for (int d = 32; d >= m.cvs; d >>= 1) v[j] += __shfl_xor(v[j], d);
+        }
+        __syncthreads();                                   // the previous sum's reads are done
+        if (lane < m.cvs) {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) red[(wave * 64 + lane) * VEC + j] = v[j];
+        }
+        __syncthreads();
+        if (dst[s]) {
+            for (int c = threadIdx.x; c < C; c += NT) {
+                const int cv = c / VEC, j = c - cv * VEC;
+                float tot = 0.f;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) tot += red[(w * 64 + cv) * VEC + j];
+                atomicAdd(&dst[s][c], (double)tot);
+            }
+        }
     }
 }
 
@@ -94,7 +131,7 @@ extern "C" int stgcn_stats_to_grads(const double* stats, float* dgamma, float* d
 struct BlockOutArgs {
     const void* o; const void* res; void* out;
     const float* s2; const float* b2; const float* sr; const float* br;
-    uint8_t* mask;       // optional: one byte per 16-byte piece, bit j = (element j of the piece > 0)
+    uint16_t* mask;      // optional: two bytes per 16-byte piece: bit j = (element j > 0), bit 8+j = (element j kept by dropout)
     size_t rows; int C; uint32_t seed, thr; float keep_scale;
 };
 
@@ -115,10 +152,11 @@ __global__ __launch_bounds__(256) void block_out_fwd_kernel(BlockOutArgs a) {
         float f[VEC], r[VEC];
         unpack16<T>(*(const i32x4*)((const T*)a.o + off), f);
         if (a.res) unpack16<T>(*(const i32x4*)((const T*)a.res + off), r);
+        const uint32_t keep = a.thr ? drop_keep_bits<VEC>(off, a.seed, a.thr) : (1u << VEC) - 1u;
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
             float q = fmaf(f[j], s2[j], b2[j]);
-            if (a.thr) q = drop_keep(off + j, a.seed, a.thr) ? q * a.keep_scale : 0.f;
+            if (a.thr) q = (keep >> j) & 1u ? q * a.keep_scale : 0.f;
             if (a.res) q += fmaf(r[j], sr[j], br[j]);
             f[j] = fmaxf(q, 0.f);
         }
@@ -130,7 +168,7 @@ __global__ __launch_bounds__(256) void block_out_fwd_kernel(BlockOutArgs a) {
             uint32_t bits = 0;
 #pragma unroll
             for (int j = 0; j < VEC; ++j) bits |= (fr[j] > 0.f ? 1u : 0u) << j;
-            a.mask[off / VEC] = (uint8_t)bits;
+            a.mask[off / VEC] = (uint16_t)(bits | (keep << 8));
         }
     }
 }
@@ -147,10 +185,12 @@ template <typename T> static inline bool ew_ok(int C) {
 }
 template <typename T> static inline int ew_rpi(int C) { int r = 256 / (C / ET<T>::VEC); return r < 1 ? 1 : r; }
 
+// 16-bit dropout threshold: an element is kept when its 16 hash bits are >= round(p * 65536); 0 = no dropout
 static inline uint32_t drop_thr(float p) {
     if (p <= 0.f) return 0u;
-    double t = (double)p * 4294967296.0;
-    if (t > 4294967295.0) t = 4294967295.0;
+    double t = (double)p * 65536.0 + 0.5;
+    if (t > 65535.0) t = 65535.0;
+    if (t < 1.0) t = 1.0;
     return (uint32_t)t;
 }
 
@@ -159,7 +199,7 @@ extern "C" int stgcn_block_out_fwd(int dtype, const void* o, const void* res, vo
                                    size_t rows, int C, float drop_p, uint32_t seed, void* stream) {
     if (!o || !out || !scale2 || !shift2 || drop_p < 0.f || drop_p >= 1.f) return STGCN_ERR_ARG;
     BlockOutArgs a;
-    a.o = o; a.res = res; a.out = out; a.mask = (uint8_t*)relu_mask; a.s2 = scale2; a.b2 = shift2; a.sr = res_scale; a.br = res_shift;
+    a.o = o; a.res = res; a.out = out; a.mask = (uint16_t*)relu_mask; a.s2 = scale2; a.b2 = shift2; a.sr = res_scale; a.br = res_shift;
     a.rows = rows; a.C = C; a.seed = seed; a.thr = drop_thr(drop_p); a.keep_scale = 1.f / (1.f - drop_p);
     if (dtype == STGCN_BF16) {
         if (!ew_ok<bf16>(C)) return STGCN_ERR_ARG;
@@ -177,7 +217,7 @@ extern "C" int stgcn_block_out_fwd(int dtype, const void* o, const void* res, vo
 //   statsr = [sum g,  sum g*rhat]   (only for the conv residual: rhat = (r - meanr) * rstdr)
 struct BlockOutBwdArgs {
     const void* dout; const float* dpool; size_t rows_per_sample;
-    const void* out; const uint8_t* mask; const void* o; const void* r;
+    const void* out; const uint16_t* mask; const void* o; const void* r;
     const float* mean2; const float* rstd2; const float* gamma2;
     const float* meanr; const float* rstdr; const float* gammar;
     double* stats2; double* statsr;
@@ -186,133 +226,203 @@ struct BlockOutBwdArgs {
     size_t rows; int C; uint32_t seed, thr; float keep_scale; double count; int training;
 };
 
-// incoming gradient of the block output: a stored tensor, and/or a per-(sample, channel) value that is
-// constant over (t, v) -- the gradient of the global average pool that follows the last block
+// The incoming gradient of the block output is a stored tensor and/or a per-(sample, channel) value that is
+// constant over (t, v) -- the gradient of the global average pool that follows the last block.
+
+// The raw operands of one 16-byte piece, fetched ahead of their use so that two rows' loads are in flight together.
+constexpr int BOB_NR = 2, BOB_NA = 2;     // rows in flight per thread: reduce pass, apply pass
+constexpr int BOB_NT = 1024, BOB_GRID = 256;   // reduce pass: threads per workgroup, workgroups
+struct BlockOutBwdPiece { i32x4 d, o, r, y; uint32_t bits; };
+
 template <typename T>
-__device__ __forceinline__ void load_dout(const BlockOutBwdArgs& a, size_t row, size_t off, int cv, float* d) {
+__device__ __forceinline__ void fetch_piece(const BlockOutBwdArgs& a, size_t off, bool want_r, BlockOutBwdPiece& p) {
     constexpr int VEC = ET<T>::VEC;
-    if (a.dout) unpack16<T>(*(const i32x4*)((const T*)a.dout + off), d);
+    if (a.dout) p.d = *(const i32x4*)((const T*)a.dout + off);
+    if (a.mask) p.bits = a.mask[off / VEC];
+    else p.y = *(const i32x4*)((const T*)a.out + off);
+    p.o = *(const i32x4*)((const T*)a.o + off);
+    if (want_r) p.r = *(const i32x4*)((const T*)a.r + off);
+}
+
+// incoming gradient of the piece: the stored tensor and/or the pooled per-(sample, channel) value
+template <typename T>
+__device__ __forceinline__ void piece_dout(const BlockOutBwdArgs& a, const BlockOutBwdPiece& p, size_t row, int cv, float* d) {
+    constexpr int VEC = ET<T>::VEC;
+    if (a.dout) unpack16<T>(p.d, d);
     else {
 #pragma unroll
         for (int j = 0; j < VEC; ++j) d[j] = 0.f;
     }
     if (a.dpool) {
-        const float* p = a.dpool + (row / a.rows_per_sample) * a.C + cv * VEC;
+        const float* q = a.dpool + (row / a.rows_per_sample) * a.C + cv * VEC;
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) d[j] += p[j];
+        for (int j = 0; j < VEC; ++j) d[j] += q[j];
     }
 }
 
-// which elements of the 16-byte piece at `off` passed the block's final ReLU: from the mask byte the forward wrote,
-// or from the stored output itself
+// bit j: element j of the piece passed the block's final ReLU; bit 8+j: it was kept by dropout.  From the mask the
+// forward wrote, or from the stored output and the dropout hash.
 template <typename T>
-__device__ __forceinline__ uint32_t relu_bits(const BlockOutBwdArgs& a, size_t off) {
+__device__ __forceinline__ uint32_t piece_mask_bits(const BlockOutBwdArgs& a, const BlockOutBwdPiece& p, size_t off) {
     constexpr int VEC = ET<T>::VEC;
-    if (a.mask) return a.mask[off / VEC];
+    if (a.mask) return p.bits;
     float y[VEC];
-    unpack16<T>(*(const i32x4*)((const T*)a.out + off), y);
-    uint32_t bits = 0;
+    unpack16<T>(p.y, y);
+    uint32_t bits = (a.thr ? drop_keep_bits<VEC>(off, a.seed, a.thr) : (1u << VEC) - 1u) << 8;
 #pragma unroll
     for (int j = 0; j < VEC; ++j) bits |= (y[j] > 0.f ? 1u : 0u) << j;
     return bits;
 }
 
-template <typename T>
-__global__ __launch_bounds__(256) void block_out_bwd_reduce_kernel(BlockOutBwdArgs a) {
+template <typename T, bool HAS_R, int NROW, int NT>
+__global__ __launch_bounds__(NT) void block_out_bwd_reduce_kernel(BlockOutBwdArgs a) {
     constexpr int VEC = ET<T>::VEC;
-    RowMap<T> m(a.C);
+    RowMap<T, NT> m(a.C);
     float sums[4][VEC];
 #pragma unroll
     for (int s = 0; s < 4; ++s)
 #pragma unroll
         for (int j = 0; j < VEC; ++j) sums[s][j] = 0.f;
     if (m.active) {
-        float mu2[VEC], rs2[VEC], mur[VEC], rsr[VEC];
-#pragma unroll
-        for (int j = 0; j < VEC; ++j) {
-            const int c = m.cv * VEC + j;
-            mu2[j] = a.mean2[c]; rs2[j] = a.rstd2[c];
-            mur[j] = a.r ? a.meanr[c] : 0.f; rsr[j] = a.r ? a.rstdr[c] : 0.f;
-        }
-        for (size_t row = (size_t)blockIdx.x * m.rpi + m.rl; row < a.rows; row += (size_t)gridDim.x * m.rpi) {
+        // the loop gathers raw moments (sum gd, sum gd*o, sum g, sum g*r) and keeps no per-channel constants in
+        // registers; sum gd*ohat = rstd * (sum gd*o - mean * sum gd) is formed once at the end
+        constexpr bool want_r = HAS_R;
+        auto consume = [&](size_t row, const BlockOutBwdPiece& p) {
             const size_t off = row * a.C + m.cv * VEC;
             float d[VEC], o[VEC], r[VEC];
-            load_dout<T>(a, row, off, m.cv, d);
-            const uint32_t pos = relu_bits<T>(a, off);
-            unpack16<T>(*(const i32x4*)((const T*)a.o + off), o);
-            if (a.r) unpack16<T>(*(const i32x4*)((const T*)a.r + off), r);
+            piece_dout<T>(a, p, row, m.cv, d);
+            const uint32_t pos = piece_mask_bits<T>(a, p, off);
+            unpack16<T>(p.o, o);
+            if (want_r) unpack16<T>(p.r, r);
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
                 const float g = (pos >> j) & 1u ? d[j] : 0.f;
                 float gd = g;
-                if (a.thr) gd = drop_keep(off + j, a.seed, a.thr) ? g * a.keep_scale : 0.f;
+                if (a.thr) gd = (pos >> (8 + j)) & 1u ? g * a.keep_scale : 0.f;
                 sums[0][j] += gd;
-                sums[1][j] += gd * ((o[j] - mu2[j]) * rs2[j]);
-                if (a.r) {
+                sums[1][j] = fmaf(gd, o[j], sums[1][j]);
+                if (want_r) {
                     sums[2][j] += g;
-                    sums[3][j] += g * ((r[j] - mur[j]) * rsr[j]);
+                    sums[3][j] = fmaf(g, r[j], sums[3][j]);
                 }
             }
+        };
+        const size_t rstep = (size_t)gridDim.x * m.rpi;
+        for (size_t row = (size_t)blockIdx.x * m.rpi + m.rl; row < a.rows; row += NROW * rstep) {
+            BlockOutBwdPiece p[NROW];
+#pragma unroll
+            for (int i = 0; i < NROW; ++i)
+                if (row + i * rstep < a.rows) fetch_piece<T>(a, (row + i * rstep) * a.C + m.cv * VEC, want_r, p[i]);
+#pragma unroll
+            for (int i = 0; i < NROW; ++i)
+                if (row + i * rstep < a.rows) consume(row + i * rstep, p[i]);
+        }
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            const int c = m.cv * VEC + j;
+            sums[1][j] = a.rstd2[c] * (sums[1][j] - a.mean2[c] * sums[0][j]);
+            if constexpr (want_r) sums[3][j] = a.rstdr[c] * (sums[3][j] - a.meanr[c] * sums[2][j]);
         }
     }
-    double* dst[4] = {a.stats2, a.stats2 + a.C, a.r ? a.statsr : nullptr, a.r ? a.statsr + a.C : nullptr};
-    block_channel_reduce<T, 4>(sums, m, a.C, dst);
+    double* dst[4] = {a.stats2, a.stats2 + a.C, HAS_R ? a.statsr : nullptr, HAS_R ? a.statsr + a.C : nullptr};
+    if constexpr (NT == 256) block_channel_reduce<T, 4>(sums, m, a.C, dst);
+    else wide_channel_reduce<T, HAS_R ? 4 : 2, NT>(sums, m, a.C, dst);
 }
 
 // pass 2: dO = BN2 backward of gd; dR = BNr backward of g (conv residual); g copy (identity residual)
-template <typename T>
-__global__ __launch_bounds__(256) void block_out_bwd_apply_kernel(BlockOutBwdArgs a) {
+template <typename T, bool HAS_R, int NROW, int NT>
+__global__ __launch_bounds__(NT) void block_out_bwd_apply_kernel(BlockOutBwdArgs a) {
     constexpr int VEC = ET<T>::VEC;
-    RowMap<T> m(a.C);
+    RowMap<T, NT> m(a.C);
     float sums[2][VEC];
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
         for (int j = 0; j < VEC; ++j) sums[s][j] = 0.f;
     if (m.active) {
-        float mu2[VEC], rs2[VEC], k2[VEC], m1[VEC], m2[VEC];
-        float mur[VEC], rsr[VEC], kr[VEC], n1[VEC], n2[VEC];
+        // k*(gd - m1 - ohat*m2) with ohat = (o - mean)*rstd, folded to three constants per channel:
+        //   k*gd + qa*o + qb,  qa = -k*m2*rstd,  qb = -k*m1 - qa*mean
+        float k2[VEC], qa2[VEC], qb2[VEC], kr[VEC], qar[VEC], qbr[VEC];
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
             const int c = m.cv * VEC + j;
-            mu2[j] = a.mean2[c]; rs2[j] = a.rstd2[c]; k2[j] = a.gamma2[c] * rs2[j];
-            m1[j] = a.training ? (float)(a.stats2[c] / a.count) : 0.f;
-            m2[j] = a.training ? (float)(a.stats2[a.C + c] / a.count) : 0.f;
-            if (a.dR) {
-                mur[j] = a.meanr[c]; rsr[j] = a.rstdr[c]; kr[j] = a.gammar[c] * rsr[j];
-                n1[j] = a.training ? (float)(a.statsr[c] / a.count) : 0.f;
-                n2[j] = a.training ? (float)(a.statsr[a.C + c] / a.count) : 0.f;
-            } else { mur[j] = rsr[j] = kr[j] = n1[j] = n2[j] = 0.f; }
+            const float rs2 = a.rstd2[c];
+            k2[j] = a.gamma2[c] * rs2;
+            const float m1 = a.training ? (float)(a.stats2[c] / a.count) : 0.f;
+            const float m2 = a.training ? (float)(a.stats2[a.C + c] / a.count) : 0.f;
+            qa2[j] = -k2[j] * m2 * rs2;
+            qb2[j] = -k2[j] * m1 - qa2[j] * a.mean2[c];
+            if constexpr (HAS_R) {
+                const float rsr = a.rstdr[c];
+                kr[j] = a.gammar[c] * rsr;
+                const float n1 = a.training ? (float)(a.statsr[c] / a.count) : 0.f;
+                const float n2 = a.training ? (float)(a.statsr[a.C + c] / a.count) : 0.f;
+                qar[j] = -kr[j] * n2 * rsr;
+                qbr[j] = -kr[j] * n1 - qar[j] * a.meanr[c];
+            } else { kr[j] = qar[j] = qbr[j] = 0.f; }
         }
-        for (size_t row = (size_t)blockIdx.x * m.rpi + m.rl; row < a.rows; row += (size_t)gridDim.x * m.rpi) {
+        constexpr bool want_r = HAS_R;
+        auto consume = [&](size_t row, const BlockOutBwdPiece& p) {
             const size_t off = row * a.C + m.cv * VEC;
             float d[VEC], o[VEC], r[VEC], gg[VEC], dr[VEC];
-            load_dout<T>(a, row, off, m.cv, d);
-            const uint32_t pos = relu_bits<T>(a, off);
-            unpack16<T>(*(const i32x4*)((const T*)a.o + off), o);
-            if (a.dR) unpack16<T>(*(const i32x4*)((const T*)a.r + off), r);
+            piece_dout<T>(a, p, row, m.cv, d);
+            const uint32_t pos = piece_mask_bits<T>(a, p, off);
+            unpack16<T>(p.o, o);
+            if (want_r) unpack16<T>(p.r, r);
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
                 const float g = (pos >> j) & 1u ? d[j] : 0.f;
                 gg[j] = g;
                 float gd = g;
-                if (a.thr) gd = drop_keep(off + j, a.seed, a.thr) ? g * a.keep_scale : 0.f;
-                const float oh = (o[j] - mu2[j]) * rs2[j];
-                o[j] = k2[j] * (gd - m1[j] - oh * m2[j]);
+                if (a.thr) gd = (pos >> (8 + j)) & 1u ? g * a.keep_scale : 0.f;
+                o[j] = fmaf(k2[j], gd, fmaf(qa2[j], o[j], qb2[j]));
                 sums[0][j] += o[j];
-                if (a.dR) {
-                    const float rh = (r[j] - mur[j]) * rsr[j];
-                    dr[j] = kr[j] * (g - n1[j] - rh * n2[j]);
+                if (want_r) {
+                    dr[j] = fmaf(kr[j], g, fmaf(qar[j], r[j], qbr[j]));
                     sums[1][j] += dr[j];
                 }
             }
             *(i32x4*)((T*)a.dO + off) = pack16<T>(o);
-            if (a.dR) *(i32x4*)((T*)a.dR + off) = pack16<T>(dr);
+            if constexpr (want_r) *(i32x4*)((T*)a.dR + off) = pack16<T>(dr);
             if (a.g) *(i32x4*)((T*)a.g + off) = pack16<T>(gg);
+        };
+        const size_t rstep = (size_t)gridDim.x * m.rpi;
+        for (size_t row = (size_t)blockIdx.x * m.rpi + m.rl; row < a.rows; row += NROW * rstep) {
+            BlockOutBwdPiece p[NROW];
+#pragma unroll
+            for (int i = 0; i < NROW; ++i)
+                if (row + i * rstep < a.rows) fetch_piece<T>(a, (row + i * rstep) * a.C + m.cv * VEC, want_r, p[i]);
+#pragma unroll
+            for (int i = 0; i < NROW; ++i)
+                if (row + i * rstep < a.rows) consume(row + i * rstep, p[i]);
         }
     }
-    double* dst[2] = {a.dbias_o, a.dR ? a.dbias_r : nullptr};
-    block_channel_reduce<T, 2>(sums, m, a.C, dst);
+    double* dst[2] = {a.dbias_o, HAS_R ? a.dbias_r : nullptr};
+    if constexpr (NT == 256) block_channel_reduce<T, 2>(sums, m, a.C, dst);
+    else wide_channel_reduce<T, HAS_R ? 2 : 1, NT>(sums, m, a.C, dst);
+}
+
+// The reduce pass reads the conv residual whenever there is one; the apply pass only when it writes dR.
+template <typename T>
+static void block_out_bwd_launch(const BlockOutBwdArgs& a, int pass, hipStream_t st) {
+    const unsigned gr = ew_grid(a.rows, ew_rpi<T>(a.C), 2048);   // every workgroup ends in C*NS double atomics
+    if (pass == 0) {
+        // the read-only pass is short enough for its closing atomics to show: with rows of <= 64 channel vectors it
+        // runs as few, large workgroups
+        const int cvs = a.C / ET<T>::VEC;
+        if (cvs <= 64 && (cvs & (cvs - 1)) == 0) {
+            const unsigned gw = ew_grid(a.rows, BOB_NT / cvs, BOB_GRID);
+            if (a.r) hipLaunchKernelGGL((block_out_bwd_reduce_kernel<T, true, BOB_NR, BOB_NT>), dim3(gw), dim3(BOB_NT), 0, st, a);
+            else hipLaunchKernelGGL((block_out_bwd_reduce_kernel<T, false, BOB_NR, BOB_NT>), dim3(gw), dim3(BOB_NT), 0, st, a);
+        } else if (a.r) hipLaunchKernelGGL((block_out_bwd_reduce_kernel<T, true, BOB_NR, 256>), dim3(gr), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((block_out_bwd_reduce_kernel<T, false, BOB_NR, 256>), dim3(gr), dim3(256), 0, st, a);
+    } else {
+        const int cvs = a.C / ET<T>::VEC;
+        if (a.dR) hipLaunchKernelGGL((block_out_bwd_apply_kernel<T, true, BOB_NA, 256>), dim3(gr), dim3(256), 0, st, a);
+        else if (cvs <= 64 && (cvs & (cvs - 1)) == 0)
+            hipLaunchKernelGGL((block_out_bwd_apply_kernel<T, false, BOB_NA, BOB_NT>), dim3(ew_grid(a.rows, BOB_NT / cvs, BOB_GRID)), dim3(BOB_NT), 0, st, a);
+        else hipLaunchKernelGGL((block_out_bwd_apply_kernel<T, false, BOB_NA, 256>), dim3(gr), dim3(256), 0, st, a);
+    }
 }
 
 extern "C" int stgcn_block_out_bwd(int dtype, int pass, const void* dout, const float* dpool, size_t rows_per_sample,
@@ -326,7 +436,7 @@ extern "C" int stgcn_block_out_bwd(int dtype, int pass, const void* dout, const 
     if (dpool && rows_per_sample == 0) return STGCN_ERR_ARG;
     if (r && (!meanr || !rstdr || !statsr)) return STGCN_ERR_ARG;
     BlockOutBwdArgs a;
-    a.dout = dout; a.dpool = dpool; a.rows_per_sample = rows_per_sample; a.out = out; a.mask = (const uint8_t*)relu_mask; a.o = o; a.r = r; a.mean2 = mean2; a.rstd2 = rstd2; a.gamma2 = gamma2;
+    a.dout = dout; a.dpool = dpool; a.rows_per_sample = rows_per_sample; a.out = out; a.mask = (const uint16_t*)relu_mask; a.o = o; a.r = r; a.mean2 = mean2; a.rstd2 = rstd2; a.gamma2 = gamma2;
     a.meanr = meanr; a.rstdr = rstdr; a.gammar = gammar; a.stats2 = stats2; a.statsr = statsr;
     a.dO = dO; a.dR = dR; a.g = g; a.dbias_o = dbias_o; a.dbias_r = dbias_r;
     a.rows = rows; a.C = C; a.seed = seed; a.thr = drop_thr(drop_p); a.keep_scale = 1.f / (1.f - drop_p);
@@ -337,14 +447,10 @@ extern "C" int stgcn_block_out_bwd(int dtype, int pass, const void* dout, const 
     hipStream_t st = (hipStream_t)stream;
     if (dtype == STGCN_BF16) {
         if (!ew_ok<bf16>(C)) return STGCN_ERR_ARG;
-        const unsigned gr = ew_grid(rows, ew_rpi<bf16>(C), 1024);   // every workgroup ends in C*NS double atomics
-        if (pass == 0) hipLaunchKernelGGL(block_out_bwd_reduce_kernel<bf16>, dim3(gr), dim3(256), 0, st, a);
-        else hipLaunchKernelGGL(block_out_bwd_apply_kernel<bf16>, dim3(gr), dim3(256), 0, st, a);
+        block_out_bwd_launch<bf16>(a, pass, st);
     } else if (dtype == STGCN_F32) {
         if (!ew_ok<float>(C)) return STGCN_ERR_ARG;
-        const unsigned gr = ew_grid(rows, ew_rpi<float>(C), 1024);
-        if (pass == 0) hipLaunchKernelGGL(block_out_bwd_reduce_kernel<float>, dim3(gr), dim3(256), 0, st, a);
-        else hipLaunchKernelGGL(block_out_bwd_apply_kernel<float>, dim3(gr), dim3(256), 0, st, a);
+        block_out_bwd_launch<float>(a, pass, st);
     } else return STGCN_ERR_ARG;
     return hipGetLastError() == hipSuccess ? STGCN_OK : STGCN_ERR_LAUNCH;
 }

@@ -103,14 +103,27 @@ template <typename T> __device__ __forceinline__ void mma_step(f32x16& acc, cons
 // Row of a 32x32 MFMA accumulator held in register r of lane half h.
 __device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
-// Dropout keep decision for the element at flat channels-last offset idx.
-__device__ __forceinline__ bool drop_keep(uint64_t idx, uint32_t seed, uint32_t thr) {
-    uint32_t x = (uint32_t)idx ^ seed;
-    x += (uint32_t)(idx >> 32) * 0x9E3779B9u;
+// Dropout keep decisions.  One 32-bit hash serves the two elements 2q and 2q+1 of the flat channels-last tensor:
+// its low half decides the even one, its high half the odd one, each kept when its 16 bits are >= thr16
+// (= round(p * 65536), so p is honoured to 1/65536).
+__device__ __forceinline__ uint32_t drop_hash(uint64_t pair, uint32_t seed) {
+    uint32_t x = (uint32_t)pair ^ seed;
+    x += (uint32_t)(pair >> 32) * 0x9E3779B9u;
     x ^= x >> 16; x *= 0x7FEB352Du;
     x ^= x >> 15; x *= 0x846CA68Bu;
     x ^= x >> 16;
-    return x >= thr;
+    return x;
+}
+// keep bits of the NV (even) consecutive elements starting at the even flat offset off: bit j = element off+j kept
+template <int NV> __device__ __forceinline__ uint32_t drop_keep_bits(uint64_t off, uint32_t seed, uint32_t thr16) {
+    uint32_t bits = 0;
+#pragma unroll
+    for (int q = 0; q < NV / 2; ++q) {
+        const uint32_t x = drop_hash((off >> 1) + q, seed);
+        bits |= ((x & 0xFFFFu) >= thr16 ? 1u : 0u) << (2 * q);
+        bits |= ((x >> 16) >= thr16 ? 1u : 0u) << (2 * q + 1);
+    }
+    return bits;
 }
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains every outstanding global load and

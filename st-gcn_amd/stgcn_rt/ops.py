@@ -291,10 +291,11 @@ def stats_to_grads(stats, Cc):
 
 
 def block_out_fwd(o, res, bn2, bnr, drop_p, seed, want_mask=False):
-    """-> out, or (out, relu_mask) with want_mask: one byte per 16-byte piece of out, bit j = element j positive."""
+    """-> out, or (out, mask) with want_mask: 16 bits per 16-byte piece of out, bit j = element j positive, bit 8+j =
+    element j kept by dropout."""
     B, Cc, T, V = o.shape
     out = new_act(B, Cc, T, V, o.dtype, o.device)
-    mask = torch.empty((B * T * V * Cc * o.element_size() // 16,), dtype=torch.uint8, device=o.device) if want_mask else None
+    mask = torch.empty((B * T * V * Cc * o.element_size() // 16,), dtype=torch.int16, device=o.device) if want_mask else None
     _launch((str(o.dtype), B * T * V, Cc, res is not None, bnr is not None), "stgcn_block_out_fwd", L.dtype_code(o.dtype), L.ptr(o), L.ptr(res), L.ptr(out), L.ptr(mask), L.ptr(bn2.scale), L.ptr(bn2.shift),
            L.ptr(bnr.scale) if bnr is not None else None, L.ptr(bnr.shift) if bnr is not None else None,
            B * T * V, Cc, float(drop_p), int(seed) & 0xFFFFFFFF, L.stream_ptr())

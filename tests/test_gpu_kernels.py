@@ -249,11 +249,15 @@ def test_block_out_and_bn_kernels(rt, Cc, rows_shape, dtype):
         tol = TOL[dtype]
         assert rel(out, out_ref) < tol, (kind, p)
         assert torch.equal(out, rt.block_out_fwd(to_dev(o, dtype), resd, bn2, bnr, p, seed))
-        # the ReLU mask: one byte per 16-byte piece of the channels-last output, bit j = element j positive
+        # the mask: 16 bits per 16-byte piece of the channels-last output, bit j = element j positive,
+        # bit 8+j = element j kept by dropout
         vec = 16 // out.element_size()
         pos = (out.permute(0, 2, 3, 1).reshape(-1, vec) > 0).to(torch.int32)
-        want = (pos << torch.arange(vec, device=pos.device, dtype=torch.int32)).sum(1).to(torch.uint8)
-        assert torch.equal(mask, want)
+        sh = torch.arange(vec, device=pos.device, dtype=torch.int32)
+        want = (pos << sh).sum(1)
+        kp = torch.ones_like(pos) if keep is None else keep.permute(0, 2, 3, 1).reshape(-1, vec).to(pos.device, torch.int32)
+        want = want | ((kp << sh).sum(1) << 8)
+        assert torch.equal(mask.to(torch.int32) & 0xFFFF, want)
 
         # backward, evaluated at the kernel's own output so the ReLU mask is identical
         outq = out.detach().to("cpu", torch.float64)

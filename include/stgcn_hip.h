@@ -56,13 +56,16 @@ int stgcn_conv_wgrad(int dtype, const void* in, const void* dout, float* dW,
 
 /* Fused graph convolution over NF = B*T frames:
  *   out[f,a,n] = sum_k sum_b adj[k][a][b] * (sum_c in[f,b,c]*w[k][n][c] + bias[k][n])  (+ add[f,a,n])
+ * add_mask (optional, with add): 16 bits per 16-byte piece of add, as written by stgcn_block_out_fwd; elements whose
+ * bit j is clear count as zero -- the gradient of an identity residual is then the block's incoming gradient itself,
+ * masked on the fly, and is never written out.
  * adj_transposed != 0 reads adj[k][b][a] in place of adj[k][a][b], so both directions take A*importance as stored:
  * Forward:  adj = A*importance, adj_transposed = 1, w[k][co][ci] = conv.weight[k*Cout+co][ci].
  * Backward: adj = A*importance, adj_transposed = 0, w[k][ci][co] = conv.weight[k*Cout+co][ci], no bias.
  * Replaces: ConvTemporalGraphical.forward -- nn.Conv2d 1x1 (net/utils/tgcn.py:60), view (tgcn.py:62-63) and
  * torch.einsum('nkctv,kvw->nctw') (tgcn.py:64) -- and its input gradient; the K*C intermediate stays in registers. */
 int stgcn_gcn_fused(int dtype, const void* in, const void* w_packed, const float* adj, int adj_transposed, const float* bias,
-                    void* out, const void* add, double* stats,
+                    void* out, const void* add, const void* add_mask, double* stats,
                     int NF, int V, int Cin, int Nout, int K, void* stream);
 
 /* dA[k][v][w] = sum_{f,co} (sum_ci w[k][co][ci] x[f,v,ci] + bias[k][co]) * dy[f,w,co]   (K <= 3 per call)

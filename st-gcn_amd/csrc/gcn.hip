@@ -21,6 +21,7 @@
 // ------------------------------------------------------------------------------------------
 struct GcnFusedArgs {
     const void* in; const void* w; const float* adj; const float* bias; void* out; const void* add;
+    const uint16_t* add_mask;    // optional: 16 bits per 16-byte piece of add; bit j clear = element j counts as zero
     double* stats;
     int NF, V, Cin, Nout, K, ntw, adj_t;
 };
@@ -152,13 +153,18 @@ __global__ __launch_bounds__(256, 2) void gcn_fused_kernel(GcnFusedArgs a) {
             for (int s = 0; s < NAP; ++s) cur[s] = *(const i32x4*)(ap + s * 32);
         }
         i32x4 addv[NADD];
+        uint32_t addm[NADD];                     // keep bits of the addend pieces (all ones without a mask)
         if (add_pf) {
 #pragma unroll
             for (int i = 0; i < NADD; ++i) {
                 const int p = lane + 64 * i;
                 addv[i] = zero16();
-                if (p < npieces && col_ok)
-                    addv[i] = *(const i32x4*)((const T*)a.add + ((size_t)f * V + (p >> pshift)) * Nout + nbase + eseg * VEC);
+                addm[i] = 0xFFu;
+                if (p < npieces && col_ok) {
+                    const size_t o = ((size_t)f * V + (p >> pshift)) * Nout + nbase + eseg * VEC;
+                    addv[i] = *(const i32x4*)((const T*)a.add + o);
+                    if (a.add_mask) addm[i] = a.add_mask[o / VEC];
+                }
             }
         }
         for (int nt = 0; nt < NTW; ++nt) {
@@ -210,7 +216,7 @@ __global__ __launch_bounds__(256, 2) void gcn_fused_kernel(GcnFusedArgs a) {
         }
         __builtin_amdgcn_wave_barrier();
         // store phase: 16-byte pieces, whole channel rows coalesced; optional addend and statistics
-        auto emit = [&](int p, bool have, i32x4 addval) {
+        auto emit = [&](int p, bool have, i32x4 addval, uint32_t addbits) {
             const int row = p >> pshift;
             i32x4 v = *(const i32x4*)(stage + row * SRS + eseg * 16);
             const size_t o = ((size_t)f * V + row) * Nout + nbase + eseg * VEC;
@@ -220,8 +226,9 @@ __global__ __launch_bounds__(256, 2) void gcn_fused_kernel(GcnFusedArgs a) {
                 if (a.add) {
                     float av[VEC];
                     unpack16<T>(have ? addval : *(const i32x4*)((const T*)a.add + o), av);
+                    const uint32_t bits = have ? addbits : (a.add_mask ? (uint32_t)a.add_mask[o / VEC] : 0xFFu);
 #pragma unroll
-                    for (int j = 0; j < VEC; ++j) fv[j] += av[j];
+                    for (int j = 0; j < VEC; ++j) fv[j] += (bits >> j) & 1u ? av[j] : 0.f;
                     v = pack16<T>(fv);
                     if constexpr (ET<T>::IS_BF16) unpack16<T>(v, fv);      // statistics of the stored values
                 }
@@ -235,10 +242,10 @@ __global__ __launch_bounds__(256, 2) void gcn_fused_kernel(GcnFusedArgs a) {
 #pragma unroll
                 for (int i = 0; i < NADD; ++i) {
                     const int p = lane + 64 * i;
-                    if (p < npieces) emit(p, add_pf, addv[i]);
+                    if (p < npieces) emit(p, add_pf, addv[i], addm[i]);
                 }
             } else {
-                for (int p = lane; p < npieces; p += 64) emit(p, false, zero16());
+                for (int p = lane; p < npieces; p += 64) emit(p, false, zero16(), 0xFFu);
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -337,11 +344,11 @@ static int gcn_fused_run(GcnFusedArgs& a, hipStream_t stream) {
 }
 
 extern "C" int stgcn_gcn_fused(int dtype, const void* in, const void* w_packed, const float* adj, int adj_transposed, const float* bias,
-                               void* out, const void* add, double* stats,
+                               void* out, const void* add, const void* add_mask, double* stats,
                                int NF, int V, int Cin, int Nout, int K, void* stream) {
     if (!in || !w_packed || !adj || !out) return STGCN_ERR_ARG;
     GcnFusedArgs a;
-    a.in = in; a.w = w_packed; a.adj = adj; a.bias = bias; a.out = out; a.add = add; a.stats = stats;
+    a.in = in; a.w = w_packed; a.adj = adj; a.bias = bias; a.out = out; a.add = add; a.add_mask = (const uint16_t*)add_mask; a.stats = stats;
     a.NF = NF; a.V = V; a.Cin = Cin; a.Nout = Nout; a.K = K; a.ntw = 1; a.adj_t = adj_transposed;
     if (dtype == STGCN_BF16) return gcn_fused_run<bf16>(a, (hipStream_t)stream);
     if (dtype == STGCN_F32) return gcn_fused_run<float>(a, (hipStream_t)stream);

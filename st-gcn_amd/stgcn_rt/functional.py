@@ -168,9 +168,12 @@ class StGcnBlockFn(torch.autograd.Function):
         f32 = lambda t: t.detach().float().contiguous()
         r_ = r if kind == "conv" else None
 
+        # identity residual: its gradient is the masked incoming gradient.  With a stored dout and the forward's bit
+        # mask, the graph-conv dX kernel masks dout itself and nothing is written for it.
+        mask_in_dx = kind == "identity" and dout is not None and dpool is None and ctx.relu_mask is not None
         dO, dR, g, stats2, statsr, dbo, dbr = P.block_out_bwd(
-            dout, out, o, r_, bn2, f32(g2), bnr, f32(gr) if kind == "conv" else None, kind == "identity", p, seed, training,
-            dpool=dpool, relu_mask=ctx.relu_mask)
+            dout, out, o, r_, bn2, f32(g2), bnr, f32(gr) if kind == "conv" else None, kind == "identity" and not mask_in_dx,
+            p, seed, training, dpool=dpool, relu_mask=ctx.relu_mask)
         dg2, db2 = P.stats_to_grads(stats2, Cout)
         dbt = dbo.float()
 
@@ -195,7 +198,10 @@ class StGcnBlockFn(torch.autograd.Function):
             dWr = P.conv_wgrad(x, dR, 1, stride, 0)
             add = P.conv_rows(dR, packs[2][1], cin_p, T, ntaps=1, stride=stride, pad=0, transposed=True)
 
-        dx = P.gcn_fused(dy, packs[0][1], A32, cin_p, add=add)
+        if mask_in_dx:
+            dx = P.gcn_fused(dy, packs[0][1], A32, cin_p, add=dout, add_mask=ctx.relu_mask)
+        else:
+            dx = P.gcn_fused(dy, packs[0][1], A32, cin_p, add=add)
         dWp, dbg = P.gcn_wgrad(x, dy, A32, need_bias=True)
         dWg = dWp[:, :, :cin_true].reshape(Wg.shape)
         dA = None

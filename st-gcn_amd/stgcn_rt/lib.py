@@ -22,7 +22,7 @@ _SIGS = {
     "stgcn_conv_rows": [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp,
                         _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "stgcn_conv_wgrad": [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp],
-    "stgcn_gcn_fused": [_i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "stgcn_gcn_fused": [_i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "stgcn_gcn_agrad": [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp],
     "stgcn_gcn_wgrad": [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp],
     "stgcn_bn_finalize": [_vp, _d, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _i, _i, _vp],

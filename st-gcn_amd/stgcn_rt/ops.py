@@ -223,12 +223,13 @@ def conv_wgrad(x, dout, ntaps, stride, pad, dil=1, pro=None):
     return dW
 
 
-def gcn_fused(x, w_packed, adj, Nout, bias=None, add=None, stats=None, adj_t=False):
-    """x [B,Cin,T,V] -> [B,Nout,T,V];  adj [K][a][b] float32 (out joint a, in joint b), or [K][b][a] with adj_t."""
+def gcn_fused(x, w_packed, adj, Nout, bias=None, add=None, stats=None, adj_t=False, add_mask=None):
+    """x [B,Cin,T,V] -> [B,Nout,T,V];  adj [K][a][b] float32 (out joint a, in joint b), or [K][b][a] with adj_t.
+    add_mask: the bit mask block_out_fwd wrote for `add`'s positions; masked-out elements of add count as zero."""
     B, Cin, T, V = x.shape
     K = adj.shape[0]
     out = new_act(B, Nout, T, V, x.dtype, x.device)
-    _launch((str(x.dtype), B * T, V, Cin, Nout, K, add is not None), "stgcn_gcn_fused", L.dtype_code(x.dtype), L.ptr(x), L.ptr(w_packed), L.ptr(adj), 1 if adj_t else 0, L.ptr(bias), L.ptr(out), L.ptr(add),
+    _launch((str(x.dtype), B * T, V, Cin, Nout, K, add is not None), "stgcn_gcn_fused", L.dtype_code(x.dtype), L.ptr(x), L.ptr(w_packed), L.ptr(adj), 1 if adj_t else 0, L.ptr(bias), L.ptr(out), L.ptr(add), L.ptr(add_mask),
            L.ptr(stats), B * T, V, Cin, Nout, K, L.stream_ptr())
     return out
 

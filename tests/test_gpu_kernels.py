@@ -195,6 +195,16 @@ def test_gcn_kernels(rt, case, dtype):
     assert rel(stats.cpu()[Cout:] / n, (y ** 2).mean(dim=(0, 2, 3))) < 2 * tol
     dxk = rt.gcn_fused(dyd, rt.pack_gcn_wt(W4, K, Cin, dtype), Ad.contiguous(), Cin)
     assert rel(dxk, dx) < tol
+    if Cin % (16 // xd.element_size()) == 0:
+        # addend masked by a block_out_fwd-style bit mask (16 bits per 16-byte piece, low byte = keep element j)
+        vec = 16 // xd.element_size()
+        addt = q(t64((B, Cin, T, V), 46), dtype)
+        gen = torch.Generator().manual_seed(47)
+        keep = torch.randint(0, 2, (B * T * V * Cin // vec, vec), generator=gen, dtype=torch.int32)
+        mbits = ((keep << torch.arange(vec, dtype=torch.int32)).sum(1) | (0x5A << 8)).to(torch.int16).to(DEV)
+        keep_t = keep.reshape(B, T, V, Cin).permute(0, 3, 1, 2).to(addt.dtype)
+        dxm = rt.gcn_fused(dyd, rt.pack_gcn_wt(W4, K, Cin, dtype), Ad.contiguous(), Cin, add=to_dev(addt, dtype), add_mask=mbits)
+        assert rel(dxm, dx + addt * keep_t) < tol
     dWk, dbk = rt.gcn_wgrad(xd, dyd, Ad.contiguous())
     assert rel(dWk.reshape(K * Cout, Cin), dW) < tol
     assert rel(dbk, db) < tol

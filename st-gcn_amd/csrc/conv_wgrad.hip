@@ -254,19 +254,21 @@ struct ConvWgradRingArgs {
 template <int STRIDE, int NT>
 __global__ __launch_bounds__(512) void conv_wgrad_ring_kernel(ConvWgradRingArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    // Stride 1: LDS rows are 128 bytes, unpadded; the 64-byte half of a row is flipped on rows with bit 1 set, so
-    // the four consecutive rows one transposed read touches per 32-lane half land on four different quarters of the
-    // bank row (conflict-free), and each lane keeps one ring address per tap that it advances by 32 rows per k-step
-    // pair with a 16-bit wrap (the ring is 64 KiB at the start of the LDS allocation).  Stride 2 computes its row
-    // offsets per read and keeps rows padded to 144 bytes, unswizzled.
-    constexpr int RS = STRIDE == 1 ? 128 : 144;
+    // LDS rows are 128 bytes, unpadded; the ring is 64 KiB at the start of the LDS allocation, so ring addresses
+    // wrap as 16-bit sums.  The 64-byte half of a row is flipped on rows with bit 1 set -- in the dout tiles always,
+    // in the ring for stride 1 -- so the four consecutive rows one transposed read touches per 32-lane half land on
+    // four different quarters of the bank row (conflict-free).  Stride 1: each lane keeps one ring address per tap
+    // and advances it by 32 rows per k-step pair.  Stride 2: the lane's row offsets of its k-steps are fixed for
+    // the whole kernel (registers); a read adds the tap's scalar base for the tile to them.
+    constexpr int RS = 128;
     constexpr int KS = STRIDE == 1 ? 16 : 8;              // k-steps (16 output rows each) per tile
     constexpr int DROWS = KS * 16;                        // dout rows per tile buffer
     constexpr int DPASS = DROWS / 64;                     // staging passes for a dout tile (64 rows per pass)
     constexpr int KW = KS / 2;                            // k-steps per wave: waves 0-3 take the even ones, 4-7 the odd
     char* ring = smem;                                   // [512 + 4][RS]: slots 512..515 mirror slots 0..3
     char* dt = smem + 516 * RS;                          // 2 x [DROWS][RS]
-    auto swz = [](int row) -> int { return STRIDE == 1 ? (row & 2) << 5 : 0; };
+    auto swz_d = [](int row) -> int { return (row & 2) << 5; };                       // dout tiles
+    auto swz = [](int row) -> int { return STRIDE == 1 ? (row & 2) << 5 : 0; };       // ring
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5;
     const int V = a.V, Rin = a.Rin, Rout = a.Rout, Cin = a.Cin, Cout = a.Cout, ntaps = a.ntaps;
@@ -274,7 +276,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_ring_kernel(ConvWgradRingArgs 
     const int co0 = blockIdx.y * 64, ci0 = blockIdx.z * 64;
     const int coh = wave & 1, cih = (wave >> 1) & 1, kg = wave >> 2;
     const int q4 = (lane & 15) >> 2, p4 = lane & 3, g1 = (lane >> 4) & 1;
-    const int acol = ((coh * 32 + 16 * g1 + 4 * p4) * 2) ^ swz(q4);   // dout rows of a read are q4 (+4) mod 8
+    const int acol = ((coh * 32 + 16 * g1 + 4 * p4) * 2) ^ swz_d(q4); // dout rows of a read are q4 (+4) mod 8
     const int bcol = (cih * 32 + 16 * g1 + 4 * p4) * 2;
     const int tile_rows = a.tile_rows;
     const int in_adv = STRIDE * tile_rows;                // input rows one tile advances by
@@ -290,6 +292,17 @@ __global__ __launch_bounds__(512) void conv_wgrad_ring_kernel(ConvWgradRingArgs 
         const int q = (int)(((float)j + 0.5f) * rV);
         return j + q * V;
     };
+
+    // stride 2: ring byte offsets (row offset * RS + column) of the two reads of each of the wave's k-steps
+    uint16_t rofs[KW][2];
+    if constexpr (STRIDE == 2) {
+#pragma unroll
+        for (int i = 0; i < KW; ++i) {
+            const int j = 16 * (2 * i + kg) + 8 * h + q4;
+            rofs[i][0] = (uint16_t)(in_off(j) * RS + bcol);
+            rofs[i][1] = (uint16_t)(in_off(j + 4) * RS + bcol);
+        }
+    }
 
     f32x16 acc[NT];
 #pragma unroll
@@ -359,7 +372,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_ring_kernel(ConvWgradRingArgs 
         auto commit_do = [&](int buf) {
 #pragma unroll
             for (int i = 0; i < DPASS; ++i)
-                *(i32x4*)(dt + (size_t)buf * DROWS * RS + (srow + 64 * i) * RS + ((sseg * 16) ^ swz(srow))) = pf[i];
+                *(i32x4*)(dt + (size_t)buf * DROWS * RS + (srow + 64 * i) * RS + ((sseg * 16) ^ swz_d(srow))) = pf[i];
         };
 
         int p0 = tile_beg * tile_rows;                    // first output row of the tile
@@ -400,8 +413,15 @@ __global__ __launch_bounds__(512) void conv_wgrad_ring_kernel(ConvWgradRingArgs 
                 const s16x4 a0 = tr(dcur + rowa * RS + acol), a1 = tr(dcur + (rowa + 4) * RS + acol);
                 return s16x8{a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
             };
-            // adv: bytes the lane's tap address moves on after the read (0 for the unused read after the last k-step)
-            auto ldb = [&](int ro0, int ro1, int t, int adv) -> s16x8 {
+            // stride 2: ring byte offset of row `first + t*V` (the tap's base for this tile), uniform
+            uint16_t tapb[NT];
+            if constexpr (STRIDE == 2) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) tapb[t] = (uint16_t)(((first + t * V) & 511) * RS);
+            }
+            // i: index of the wave's k-step within the tile.  adv (stride 1): bytes the lane's tap address moves on
+            // after the read (0 for the unused read after the last k-step)
+            auto ldb = [&](int i, int t, int adv) -> s16x8 {
                 const char* p0;
                 const char* p1;
                 if constexpr (STRIDE == 1) {
@@ -409,40 +429,34 @@ __global__ __launch_bounds__(512) void conv_wgrad_ring_kernel(ConvWgradRingArgs 
                     p1 = p0 + 4 * RS;                       // rows +4: the mirror slots cover the wrap
                     badr[t] = (uint16_t)(badr[t] + (uint16_t)adv);
                 } else {
-                    const int r0 = (first + ro0 + t * V) & 511, r1 = (first + ro1 + t * V) & 511;
-                    p0 = ring + r0 * RS + bcol; p1 = ring + r1 * RS + bcol;
+                    p0 = ring + (uint32_t)(uint16_t)(rofs[i][0] + tapb[t]);
+                    p1 = ring + (uint32_t)(uint16_t)(rofs[i][1] + tapb[t]);
                 }
                 const s16x4 b0 = tr(p0), b1 = tr(p1);
                 return s16x8{b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
             };
             constexpr int ADV = 32 * RS;                  // a wave's next k-step is 32 rows on
-            constexpr int STEP_UNROLL = NT == 1 ? KW / 2 : 1;
-            int ro0 = in_off(16 * kg + 8 * h + q4), ro1 = in_off(16 * kg + 8 * h + q4 + 4);
-            s16x8 af = lda(kg), bc = ldb(ro0, ro1, 0, ADV);
-#pragma unroll 1
-            for (int hs = 0; hs < 2; ++hs) {
+            constexpr int STEP_UNROLL = (STRIDE == 2 || NT == 1) ? KW : 1;
+            s16x8 af = lda(kg), bc = ldb(0, 0, ADV);
 #pragma unroll STEP_UNROLL
-                for (int sj = 0; sj < KW / 2; ++sj) {
-                    // the step after the tile's last wraps to the first: its reads are valid and unused
-                    const int adv0 = (hs == 1 && sj == KW / 2 - 1) ? 0 : ADV;
-                    const int sn = 2 * ((hs * (KW / 2) + sj + 1) & (KW - 1)) + kg;
-                    const int jn = 16 * sn + 8 * h + q4;
-                    const int rn0 = in_off(jn), rn1 = in_off(jn + 4);
-                    s16x8 afn = af;
+            for (int i = 0; i < KW; ++i) {
+                // the step after the tile's last wraps to the first: its reads are valid and unused
+                const int adv0 = i == KW - 1 ? 0 : ADV;
+                const int in = (i + 1) & (KW - 1);
+                s16x8 afn = af;
 #pragma unroll
-                    for (int t = 0; t < NT; ++t) {
-                        s16x8 bn;
-                        if (t + 1 < NT) bn = ldb(ro0, ro1, t + 1, ADV);
-                        else { afn = lda(sn); bn = ldb(rn0, rn1, 0, adv0); }
-                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bc, acc[t], 0, 0, 0);
-                        if (t + 1 < NT) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                        else __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                        bc = bn;
-                    }
-                    af = afn; ro0 = rn0; ro1 = rn1;
+                for (int t = 0; t < NT; ++t) {
+                    s16x8 bn;
+                    if (t + 1 < NT) bn = ldb(i, t + 1, ADV);
+                    else { afn = lda(2 * in + kg); bn = ldb(in, 0, adv0); }
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bc, acc[t], 0, 0, 0);
+                    if (t + 1 < NT) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    else __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    bc = bn;
                 }
-                if (hs == 0 && more) {
+                af = afn;
+                if (i == KW / 2 - 1 && more) {
                     commit_do(cur ^ 1);                   // last read a tile ago: every wave has passed a barrier since
                     fetch_in(pnew);
                 }
@@ -513,7 +527,7 @@ static int conv_wgrad_ring_try(const void* in, const void* dout, float* dW, cons
     segs = ceil_div_i(ntiles, tps);
     a.tiles_per_seg = tps; a.segs_per_sample = segs; a.nruns = B * segs;
     if (nwg > a.nruns) nwg = a.nruns;
-    const size_t lds = stride == 1 ? 516 * 128 + 2 * 256 * 128 : 516 * 144 + 2 * 128 * 144;
+    const size_t lds = 516 * 128 + 2 * (stride == 1 ? 256 : 128) * 128;
     const int variant = (stride - 1) * 2 + (ntaps == 9 ? 1 : 0);
     const void* fns[4] = {(const void*)conv_wgrad_ring_kernel<1, 1>, (const void*)conv_wgrad_ring_kernel<1, 9>,
                           (const void*)conv_wgrad_ring_kernel<2, 1>, (const void*)conv_wgrad_ring_kernel<2, 9>};

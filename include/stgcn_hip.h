@@ -119,6 +119,15 @@ int stgcn_bn_bwd_apply(int dtype, const void* g, const void* y, void* dy, const 
                        const float* mean, const float* rstd, const double* stats, double count,
                        size_t rows, int C, int training, void* stream);
 
+/* Batch input augmentation, x and out [N][C][T][V*M] float32: out frame t of clip n shows input frame t + shift[n]
+ * (zeros outside [0, Tin)); then, when ca is given, channels 0/1 of every frame f = n*Tout + t become
+ * x' = ca[f]*x - sa[f]*y + tx[f], y' = sa[f]*x + ca[f]*y + ty[f]  (ca = s*cos a, sa = s*sin a).
+ * Replaces: feeder/tools.py random_choose / auto_pading (tools.py:31-54) and random_move's transformation
+ * (tools.py:96-107) applied per clip on the host; the random draws stay on the host (feeder.tools.choose_shift,
+ * move_params). */
+int stgcn_augment(const float* in, float* out, const int* shift, const float* ca, const float* sa,
+                  const float* tx, const float* ty, int N, int C, int Tin, int Tout, int VM, void* stream);
+
 /* data_bn: BatchNorm1d over channel v*C+c of x[N,C,T,V,M] (float32) and the two permutes around it.
  * Replaces: net/st_gcn.py:72-78 (output is the channels-last [N*M][T][V][Cp] activation, Cp >= C zero padded). */
 int stgcn_data_bn_stats(const float* x, double* stats, int N, int C, int T, int V, int M, void* stream);

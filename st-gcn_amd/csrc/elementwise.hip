@@ -578,6 +578,46 @@ __global__ __launch_bounds__(256) void data_bn_bwd_kernel(const T* dx0, const fl
     for (int i = threadIdx.x; i < 2 * VC; i += blockDim.x) atomicAdd(&stats[i], (double)sh[i]);
 }
 
+// ------------------------------------------------------------------------------------------
+// Input augmentation for a whole batch: temporal window (crop or zero-pad by a per-clip frame shift) followed by
+// a per-frame rotation / scaling / translation of channels 0 and 1.  x, out: [N][C][T][V*M] float32.
+__global__ __launch_bounds__(256) void augment_kernel(const float* in, float* out, const int* shift, const float* ca, const float* sa,
+                                                      const float* tx, const float* ty, int N, int C, int Tin, int Tout, int VM) {
+    const size_t total = (size_t)N * Tout * VM;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        const int vm = (int)(e % VM);
+        const size_t nt = e / VM;
+        const int t = (int)(nt % Tout), n = (int)(nt / Tout);
+        const int src = t + (shift ? shift[n] : 0);
+        const bool inside = src >= 0 && src < Tin;
+        const float* ip = in + ((size_t)n * C * Tin + (inside ? src : 0)) * VM + vm;
+        float* op = out + ((size_t)n * C * Tout + t) * VM + vm;
+        float x = 0.f, y = 0.f;
+        if (C > 0) x = inside ? ip[0] : 0.f;
+        if (C > 1) y = inside ? ip[(size_t)Tin * VM] : 0.f;
+        if (ca && C > 1) {
+            const size_t f = (size_t)n * Tout + t;
+            const float c = ca[f], s = sa[f];
+            const float nx = c * x - s * y + tx[f];
+            const float ny = s * x + c * y + ty[f];
+            x = nx; y = ny;
+        }
+        if (C > 0) op[0] = x;
+        if (C > 1) op[(size_t)Tout * VM] = y;
+        for (int ch = 2; ch < C; ++ch) op[(size_t)ch * Tout * VM] = inside ? ip[(size_t)ch * Tin * VM] : 0.f;
+    }
+}
+extern "C" int stgcn_augment(const float* in, float* out, const int* shift, const float* ca, const float* sa,
+                             const float* tx, const float* ty, int N, int C, int Tin, int Tout, int VM, void* stream) {
+    if (!in || !out || N < 1 || C < 1 || Tin < 1 || Tout < 1 || VM < 1) return STGCN_ERR_ARG;
+    if (ca && (!sa || !tx || !ty)) return STGCN_ERR_ARG;
+    const size_t total = (size_t)N * Tout * VM;
+    size_t g = (total + 255) / 256;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(augment_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, in, out, shift, ca, sa, tx, ty, N, C, Tin, Tout, VM);
+    return hipGetLastError() == hipSuccess ? STGCN_OK : STGCN_ERR_LAUNCH;
+}
+
 extern "C" int stgcn_data_bn_stats(const float* x, double* stats, int N, int C, int T, int V, int M, void* stream) {
     if (!x || !stats || N < 1 || C < 1 || T < 1 || V < 1 || M < 1) return STGCN_ERR_ARG;
     int gy = (T + 31) / 32; if (gy > 16) gy = 16;

@@ -338,3 +338,32 @@ def bn_bwd_apply(g, y, gamma, bn, stats, training, out=None):
 def sgd_step(params, grads, mom, lr, momentum, weight_decay, nesterov, first_step, grad_scale=1.0):
     L.call("stgcn_sgd_step", L.ptr(params), L.ptr(grads), L.ptr(mom), params.numel(), float(lr), float(momentum), float(weight_decay),
            1 if nesterov else 0, 1 if first_step else 0, float(grad_scale), L.stream_ptr())
+
+
+def augment_batch(x, window=None, shift=None, move=None):
+    """Batched input augmentation on the GPU: x [N,C,T,V,M] float32 -> [N,C,window or T,V,M].
+
+    shift: int tensor/sequence [N], output frame t shows input frame t + shift[n] (zeros outside) -- the draw of
+    feeder.tools.choose_shift per clip.  move: (a, s, tx, ty), each [N, Tout] (angles in radians) -- the draws of
+    feeder.tools.move_params per clip; the transformation itself runs in the kernel."""
+    check_f32 = x.dtype == torch.float32 and x.is_cuda and x.is_contiguous()
+    if not check_f32:
+        raise RuntimeError("augment_batch wants a contiguous float32 CUDA tensor [N,C,T,V,M]")
+    N, Cc, T, V, M = x.shape
+    Tout = int(window) if window else T
+    out = torch.empty((N, Cc, Tout, V, M), dtype=torch.float32, device=x.device)
+    sh = None
+    if shift is not None:
+        sh = torch.as_tensor(shift, dtype=torch.int32).to(x.device).contiguous()
+        if sh.numel() != N:
+            raise ValueError("shift wants one entry per clip")
+    ca = sa = tx = ty = None
+    if move is not None:
+        a, s, tx_, ty_ = [torch.as_tensor(v, dtype=torch.float64).reshape(N, Tout) for v in move]
+        ca = (torch.cos(a) * s).float().to(x.device).contiguous()
+        sa = (torch.sin(a) * s).float().to(x.device).contiguous()
+        tx = tx_.float().to(x.device).contiguous()
+        ty = ty_.float().to(x.device).contiguous()
+    L.call("stgcn_augment", L.ptr(x), L.ptr(out), L.ptr(sh), L.ptr(ca), L.ptr(sa), L.ptr(tx), L.ptr(ty),
+           N, Cc, T, Tout, V * M, L.stream_ptr())
+    return out

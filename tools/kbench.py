@@ -95,6 +95,23 @@ def make(case, dtype):
                 rows, Cc, 0.5, 1234, float(rows), 1, L.stream_ptr()]
         keepalive = (o, dout, r, mask, acc, dO, dR, g, bn2, bnr, g2, gr)
         return lambda: (L.call("stgcn_block_out_bwd", *args), keepalive)[0]
+    if name == "bnbwd":                                  # bn_bwd_apply
+        Cc, Tt = Cin, Tin
+        g, y = act(Cc, Tt, dtype), act(Cc, Tt, dtype)
+        rows = g.shape[0] * Tt * V
+        mk = lambda: (torch.rand((Cc,), device=DEV) + 0.5)
+        bn = R.bn_finalize(torch.rand((2, Cc), dtype=torch.float64, device=DEV) * rows, rows, mk(), mk(), torch.zeros(Cc, device=DEV), torch.ones(Cc, device=DEV), True)
+        st = torch.rand((2 * Cc,), dtype=torch.float64, device=DEV)
+        gm = mk()
+        out = torch.empty_like(g)
+        return lambda: R.bn_bwd_apply(g, y, gm, bn, st, True, out=out)
+    if name == "bofwd":                                  # block_out_fwd with identity residual and mask
+        Cc, Tt = Cin, Tin
+        o, res = act(Cc, Tt, dtype), act(Cc, Tt, dtype)
+        rows = o.shape[0] * Tt * V
+        mk = lambda: (torch.rand((Cc,), device=DEV) + 0.5)
+        bn = R.bn_finalize(torch.rand((2, Cc), dtype=torch.float64, device=DEV) * rows, rows, mk(), mk(), torch.zeros(Cc, device=DEV), torch.ones(Cc, device=DEV), True)
+        return lambda: R.block_out_fwd(o, res, bn, None, 0.5, 1234, want_mask=True)
     raise SystemExit("unknown case " + case)
 
 

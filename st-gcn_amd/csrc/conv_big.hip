@@ -239,48 +239,37 @@ __global__ __launch_bounds__(WR * WC * 64) void conv_big_kernel(ConvBigArgs a) {
                     lds_barrier();                         // weight tile of this step (and a new window) visible
                     const int wnext = wcur == 2 ? 0 : wcur + 1;
                     const int wstore = wnext == 2 ? 0 : wnext + 1;
-                    if constexpr (true) {
-                        if (tapi == 0) {                   // first step on a new window: nothing was prefetched
-                            a_offsets(0, aoff);
-                            load_frag(fa, aoff, wcur, 0);
-                        }
-                        const bool chain = tapi + 1 < ntaps;   // the next step reads the same window
-                        // 4 k-steps; the fragments of the next one (or of the next step's first) ride under the MFMAs.
-                        // The step's bookkeeping (publishing the weight tile of step +2, fetching that of step +3,
-                        // the next tap's row offsets) sits behind the first MFMAs, not in front of them: both waves
-                        // of a SIMD leave the barrier together, and whatever precedes the first MFMA idles the pipe.
-                        __builtin_amdgcn_sched_barrier(0);
-                        load_frag(fb, aoff, wcur, 1);
-                        mma_frag(fa);
-                        CB_INTERLEAVE(MT + NT, MT * NT)
-                        __builtin_amdgcn_sched_barrier(0);
-                        store_w(wstore);                   // tile of step +2; its buffer was read during step -1
-                        load_frag(fa, aoff, wcur, 2);
-                        mma_frag(fb);
-                        CB_INTERLEAVE(MT + NT, MT * NT)
-                        __builtin_amdgcn_sched_barrier(0);
-                        load_w_next();                     // tile of step +3
-                        if (chain) a_offsets(tapi + 1, aoff_n);
-                        load_frag(fb, aoff, wcur, 3);
-                        mma_frag(fa);
-                        CB_INTERLEAVE(MT + NT, MT * NT)
-                        __builtin_amdgcn_sched_barrier(0);
-                        if (chain) load_frag(fa, aoff_n, wnext, 0);
-                        mma_frag(fb);
-                        CB_INTERLEAVE(MT + NT, MT * NT)
-                        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                        for (int m = 0; m < MT; ++m) aoff[m] = aoff_n[m];
-                    } else {
-                        // the 8-accumulator tile leaves too few registers for a second fragment set: plain k-step
-                        // loop, the compiler interleaves its 24 reads with the 32 MFMAs
-                        a_offsets(tapi, aoff);
-#pragma unroll
-                        for (int s = 0; s < 4; ++s) {
-                            load_frag(fa, aoff, wcur, s);
-                            mma_frag(fa);
-                        }
+                    if (tapi == 0) {                   // first step on a new window: nothing was prefetched
+                        a_offsets(0, aoff);
+                        load_frag(fa, aoff, wcur, 0);
                     }
+                    const bool chain = tapi + 1 < ntaps;   // the next step reads the same window
+                    // 4 k-steps; the fragments of the next one (or of the next step's first) ride under the MFMAs.
+                    // The step's bookkeeping (publishing the weight tile of step +2, fetching that of step +3,
+                    // the next tap's row offsets) sits behind the first MFMAs, not in front of them: both waves
+                    // of a SIMD leave the barrier together, and whatever precedes the first MFMA idles the pipe.
+                    __builtin_amdgcn_sched_barrier(0);
+                    load_frag(fb, aoff, wcur, 1);
+                    mma_frag(fa);
+                    CB_INTERLEAVE(MT + NT, MT * NT)
+                    __builtin_amdgcn_sched_barrier(0);
+                    store_w(wstore);                   // tile of step +2; its buffer was read during step -1
+                    load_frag(fa, aoff, wcur, 2);
+                    mma_frag(fb);
+                    CB_INTERLEAVE(MT + NT, MT * NT)
+                    __builtin_amdgcn_sched_barrier(0);
+                    load_w_next();                     // tile of step +3
+                    if (chain) a_offsets(tapi + 1, aoff_n);
+                    load_frag(fb, aoff, wcur, 3);
+                    mma_frag(fa);
+                    CB_INTERLEAVE(MT + NT, MT * NT)
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (chain) load_frag(fa, aoff_n, wnext, 0);
+                    mma_frag(fb);
+                    CB_INTERLEAVE(MT + NT, MT * NT)
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) aoff[m] = aoff_n[m];
                     wcur = wnext;
                 }
             }

@@ -80,13 +80,13 @@ __global__ __launch_bounds__(WR * WC * 64) void conv_big_kernel(ConvBigArgs a) {
     const int eseg = tid % EPR, erow = tid / EPR;          // epilogue: ERP rows per pass, fixed 8 channels
     const bool has_pro = a.pro_scale != nullptr;
 
-    float e_sc[VEC], e_sh[VEC], e_mu[VEC], e_rs[VEC], s1[VEC], s2[VEC];
+    float e_sc[VEC], e_sh[VEC], s1[VEC], s2[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
         s1[j] = 0.f; s2[j] = 0.f;
         const int co = co0 + eseg * VEC + j;
-        if (EPI == 1 && co < Cout) { e_sc[j] = a.ep_scale[co]; e_sh[j] = a.ep_shift[co]; e_mu[j] = a.ep_mean[co]; e_rs[j] = a.ep_rstd[co]; }
-        else { e_sc[j] = e_sh[j] = e_mu[j] = e_rs[j] = 0.f; }
+        if (EPI == 1 && co < Cout) { e_sc[j] = a.ep_scale[co]; e_sh[j] = a.ep_shift[co]; }
+        else { e_sc[j] = e_sh[j] = 0.f; }
     }
     float biasv[NT];
 #pragma unroll
@@ -327,7 +327,7 @@ __global__ __launch_bounds__(WR * WC * 64) void conv_big_kernel(ConvBigArgs a) {
                             for (int j = 0; j < VEC; ++j) {
                                 f[j] = (fmaf(y[j], e_sc[j], e_sh[j]) > 0.f) ? f[j] : 0.f;
                                 s1[j] += f[j];
-                                s2[j] += f[j] * ((y[j] - e_mu[j]) * e_rs[j]);
+                                s2[j] = fmaf(f[j], y[j], s2[j]);        // raw moment; centred once at the end of the kernel
                             }
                             v = pack16<T>(f);
                         } else {
@@ -351,9 +351,15 @@ __global__ __launch_bounds__(WR * WC * 64) void conv_big_kernel(ConvBigArgs a) {
         if (tid < 2 * BN) {
             const int which = tid / BN, c = tid % BN;     // which: 0 = s1, 1 = s2 ; c = channel within the tile
             const int sg = c / VEC, j = c % VEC;
-            float t = 0.f;
+            float t = 0.f, t1 = 0.f;
             for (int r = 0; r < ERP; ++r) t += red[(r * EPR + sg) * 16 + which * 8 + j];
-            if (co0 + c < Cout) atomicAdd(&a.stats[which * Cout + co0 + c], (double)t);
+            double tv = (double)t;
+            if (EPI == 1 && which == 1 && co0 + c < Cout) {
+                // the epilogue gathered sum g*y; the statistic is sum g*yhat = rstd * (sum g*y - mean * sum g)
+                for (int r = 0; r < ERP; ++r) t1 += red[(r * EPR + sg) * 16 + j];
+                tv = (double)a.ep_rstd[co0 + c] * (tv - (double)a.ep_mean[co0 + c] * (double)t1);
+            }
+            if (co0 + c < Cout) atomicAdd(&a.stats[which * Cout + co0 + c], tv);
         }
     }
 }

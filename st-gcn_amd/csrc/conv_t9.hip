@@ -127,13 +127,13 @@ __global__ __launch_bounds__(T9_NT) void conv_t9_kernel(ConvT9Args a) {
         }
     }
 
-    float e_sc[8], e_sh[8], e_mu[8], e_rs[8], s1[8], s2[8];
+    float e_sc[8], e_sh[8], s1[8], s2[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         s1[j] = 0.f; s2[j] = 0.f;
         const int co = co0 + sseg * 8 + j;
-        if (EPI == 1 && co < Cout) { e_sc[j] = a.ep_scale[co]; e_sh[j] = a.ep_shift[co]; e_mu[j] = a.ep_mean[co]; e_rs[j] = a.ep_rstd[co]; }
-        else { e_sc[j] = e_sh[j] = e_mu[j] = e_rs[j] = 0.f; }
+        if (EPI == 1 && co < Cout) { e_sc[j] = a.ep_scale[co]; e_sh[j] = a.ep_shift[co]; }
+        else { e_sc[j] = e_sh[j] = 0.f; }
     }
     float biasv[2];
 #pragma unroll
@@ -232,7 +232,7 @@ __global__ __launch_bounds__(T9_NT) void conv_t9_kernel(ConvT9Args a) {
                     for (int j = 0; j < 8; ++j) {
                         f[j] = (fmaf(y[j], e_sc[j], e_sh[j]) > 0.f) ? f[j] : 0.f;
                         s1[j] += f[j];
-                        s2[j] += f[j] * ((y[j] - e_mu[j]) * e_rs[j]);
+                        s2[j] = fmaf(f[j], y[j], s2[j]);        // raw moment; centred once at the end of the kernel
                     }
                     v = pack16<bf16>(f);
                 } else {
@@ -257,9 +257,15 @@ __global__ __launch_bounds__(T9_NT) void conv_t9_kernel(ConvT9Args a) {
         if (tid < 128) {
             const int which = tid >> 6, c = tid & 63;     // which: 0 = s1, 1 = s2 ; c = channel within the tile
             const int sg = c >> 3, j = c & 7;
-            float t = 0.f;
+            float t = 0.f, t1 = 0.f;
             for (int r = 0; r < SROWS; ++r) t += red[(r * 8 + sg) * 16 + which * 8 + j];
-            if (co0 + c < Cout) atomicAdd(&a.stats[which * Cout + co0 + c], (double)t);
+            double tv = (double)t;
+            if (EPI == 1 && which == 1 && co0 + c < Cout) {
+                // the epilogue gathered sum g*y; the statistic is sum g*yhat = rstd * (sum g*y - mean * sum g)
+                for (int r = 0; r < SROWS; ++r) t1 += red[(r * 8 + sg) * 16 + j];
+                tv = (double)a.ep_rstd[co0 + c] * (tv - (double)a.ep_mean[co0 + c] * (double)t1);
+            }
+            if (co0 + c < Cout) atomicAdd(&a.stats[which * Cout + co0 + c], tv);
         }
     }
 }

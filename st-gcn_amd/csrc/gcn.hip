@@ -80,8 +80,10 @@ __device__ __forceinline__ void chain_mma(f32x16& accy, const f32x16& accz, cons
 // NA = 32-byte k-steps per input row (Cin / KSTEP) as a compile-time constant, so the projection is a straight run
 // of MFMAs with its LDS reads issued ahead; NA = 0 is the any-width fallback (runtime loop, operands fetched per
 // step).  With NA <= 16 the next frame's rows are fetched into a second register set while this frame computes.
-template <typename T, int NA>
-__global__ __launch_bounds__(256, 2) void gcn_fused_kernel(GcnFusedArgs a) {
+// ADD: the launch has an addend; without one the prefetch registers of the addend are not allocated, which lets the
+// narrow forms (NA <= 4) run three workgroups per CU.
+template <typename T, int NA, bool ADD>
+__global__ __launch_bounds__(256, (NA >= 1 && NA <= 4 && (!ADD || ET<T>::IS_BF16)) ? 3 : 2) void gcn_fused_kernel(GcnFusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int ES = ET<T>::ES;
     constexpr int KSTEP = ET<T>::KSTEP;
@@ -90,7 +92,7 @@ __global__ __launch_bounds__(256, 2) void gcn_fused_kernel(GcnFusedArgs a) {
     constexpr int NPASS = NA == 0 ? 0 : (NA + 15) / 16;
     constexpr bool PF = NPASS == 1 && NA <= 8;                  // prefetch the next frame (register budget)
     constexpr bool ONCE = NPASS == 1 && !PF;                    // fragments loaded once per frame, no prefetch
-    constexpr int NADD = 8;                                     // addend pieces prefetched per lane
+    constexpr int NADD = ET<T>::IS_BF16 ? 4 : 8;                // addend pieces prefetched per lane (covers V * NC / VEC <= 64 * NADD)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5;
     const int V = a.V, K = a.K, Cin = a.Cin, Nout = a.Nout, NF = a.NF;
@@ -132,7 +134,7 @@ __global__ __launch_bounds__(256, 2) void gcn_fused_kernel(GcnFusedArgs a) {
     const int ncols = min(NC, Nout - nbase);
     const int npieces = V << pshift;
     const bool col_ok = eseg * VEC < ncols;
-    const bool add_pf = a.add != nullptr && npieces <= NADD * 64;
+    const bool add_pf = ADD && npieces <= NADD * 64;
     float st1[VEC], st2[VEC];
 #pragma unroll
     for (int i = 0; i < VEC; ++i) { st1[i] = 0.f; st2[i] = 0.f; }
@@ -152,8 +154,8 @@ __global__ __launch_bounds__(256, 2) void gcn_fused_kernel(GcnFusedArgs a) {
 #pragma unroll
             for (int s = 0; s < NAP; ++s) cur[s] = *(const i32x4*)(ap + s * 32);
         }
-        i32x4 addv[NADD];
-        uint32_t addm[NADD];                     // keep bits of the addend pieces (all ones without a mask)
+        i32x4 addv[ADD ? NADD : 1];
+        uint32_t addm[ADD ? NADD : 1];           // keep bits of the addend pieces (all ones without a mask)
         if (add_pf) {
 #pragma unroll
             for (int i = 0; i < NADD; ++i) {
@@ -220,10 +222,10 @@ __global__ __launch_bounds__(256, 2) void gcn_fused_kernel(GcnFusedArgs a) {
             const int row = p >> pshift;
             i32x4 v = *(const i32x4*)(stage + row * SRS + eseg * 16);
             const size_t o = ((size_t)f * V + row) * Nout + nbase + eseg * VEC;
-            if (a.add || a.stats) {
+            if (ADD || a.stats) {
                 float fv[VEC];
                 unpack16<T>(v, fv);
-                if (a.add) {
+                if constexpr (ADD) {
                     float av[VEC];
                     unpack16<T>(have ? addval : *(const i32x4*)((const T*)a.add + o), av);
                     const uint32_t bits = have ? addbits : (a.add_mask ? (uint32_t)a.add_mask[o / VEC] : 0xFFu);
@@ -242,7 +244,7 @@ __global__ __launch_bounds__(256, 2) void gcn_fused_kernel(GcnFusedArgs a) {
 #pragma unroll
                 for (int i = 0; i < NADD; ++i) {
                     const int p = lane + 64 * i;
-                    if (p < npieces) emit(p, add_pf, addv[i], addm[i]);
+                    if (p < npieces) emit(p, add_pf, addv[ADD ? i : 0], addm[ADD ? i : 0]);
                 }
             } else {
                 for (int p = lane; p < npieces; p += 64) emit(p, false, zero16(), 0xFFu);
@@ -302,13 +304,17 @@ __global__ __launch_bounds__(256, 2) void gcn_fused_kernel(GcnFusedArgs a) {
     }
 }
 
-template <typename T, int NA>
-static int gcn_fused_launch(GcnFusedArgs& a, dim3 grid, size_t lds, hipStream_t stream) {
-    auto kern = gcn_fused_kernel<T, NA>;
+template <typename T, int NA, bool ADD>
+static int gcn_fused_launch2(GcnFusedArgs& a, dim3 grid, size_t lds, hipStream_t stream) {
+    auto kern = gcn_fused_kernel<T, NA, ADD>;
     static bool set = false;
     if (!set) { if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return STGCN_ERR_LAUNCH; set = true; }
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, a);
     return hipGetLastError() == hipSuccess ? STGCN_OK : STGCN_ERR_LAUNCH;
+}
+template <typename T, int NA>
+static int gcn_fused_launch(GcnFusedArgs& a, dim3 grid, size_t lds, hipStream_t stream) {
+    return a.add ? gcn_fused_launch2<T, NA, true>(a, grid, lds, stream) : gcn_fused_launch2<T, NA, false>(a, grid, lds, stream);
 }
 
 template <typename T>
@@ -328,7 +334,9 @@ static int gcn_fused_run(GcnFusedArgs& a, hipStream_t stream) {
     a.ntw = ntw;
     const int gy = ceil_div_i(a.Nout, ntw * 32);
     // persistent waves: as many workgroups as stay resident (2 per CU when the LDS image allows it)
-    const int resident = (lds <= 80 * 1024 ? 2 : 1) * 256;
+    const int na = a.Cin / KSTEP;
+    const int per_cu = ((!a.add || ET<T>::IS_BF16) && na >= 1 && na <= 4 && 3 * lds <= 160 * 1024) ? 3 : lds <= 80 * 1024 ? 2 : 1;
+    const int resident = per_cu * 256;
     int gx = max(1, resident / gy);
     if (gx > ceil_div_i(a.NF, 4)) gx = ceil_div_i(a.NF, 4);
     const dim3 grid((unsigned)gx, (unsigned)gy);

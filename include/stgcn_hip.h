@@ -101,8 +101,9 @@ int stgcn_block_out_fwd(int dtype, const void* o, const void* res, void* out, vo
                         size_t rows, int C, float drop_p, uint32_t seed, void* stream);
 
 /* Backward of the stage above.  pass 0: per-channel sums (stats2, statsr).  pass 1: dO (BatchNorm backward of the
- * main branch), dR (same for a conv residual), g (= masked incoming gradient, for an identity residual), and the
- * bias gradients of the two convolutions (dbias_*).  The incoming gradient is dout and/or dpool (float32 [B][C],
+ * main branch), dR (same for a conv residual), g (= masked incoming gradient, for an identity residual), the
+ * bias gradients of the two convolutions (dbias_*: float32 sums accumulated with atomics, zeroed by the caller) and,
+ * when asked for, the BatchNorm parameter gradients read off the sums of pass 0 (dbeta = sum, dgamma = sum*xhat).  The incoming gradient is dout and/or dpool (float32 [B][C],
  * constant over (t,v): the gradient of the global average pool).  The ReLU and dropout decisions come from relu_mask when
  * given (then out may be null), else from out and the dropout hash.
  * Replaces: autograd of net/st_gcn.py:169-170, 193-197 (and of F.avg_pool2d, st_gcn.py:85, for dpool). */
@@ -111,13 +112,15 @@ int stgcn_block_out_bwd(int dtype, int pass, const void* dout, const float* dpoo
                         const float* mean2, const float* rstd2, const float* gamma2,
                         const float* meanr, const float* rstdr, const float* gammar,
                         double* stats2, double* statsr, void* dO, void* dR, void* g,
-                        double* dbias_o, double* dbias_r,
+                        float* dbias_o, float* dbias_r,
+                        float* dgamma2, float* dbeta2, float* dgammar, float* dbetar,
                         size_t rows, int C, float drop_p, uint32_t seed, double count, int training, void* stream);
 
-/* dy = gamma*rstd*(g - S1/n - yhat*S2/n)  (eval: g*gamma*rstd).  Replaces: autograd of BatchNorm2d (st_gcn.py:160). */
+/* dy = gamma*rstd*(g - S1/n - yhat*S2/n)  (eval: g*gamma*rstd); optionally also dbeta = S1, dgamma = S2 as float32.
+ * Replaces: autograd of BatchNorm2d (st_gcn.py:160). */
 int stgcn_bn_bwd_apply(int dtype, const void* g, const void* y, void* dy, const float* gamma,
                        const float* mean, const float* rstd, const double* stats, double count,
-                       size_t rows, int C, int training, void* stream);
+                       float* dgamma, float* dbeta, size_t rows, int C, int training, void* stream);
 
 /* Batch input augmentation, x and out [N][C][T][V*M] float32: out frame t of clip n shows input frame t + shift[n]
  * (zeros outside [0, Tin)); then, when ca is given, channels 0/1 of every frame f = n*Tout + t become

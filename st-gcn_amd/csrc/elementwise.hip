@@ -18,8 +18,8 @@ template <typename T, int NT = 256> struct RowMap {
 };
 
 // sums[j] (per thread, NS floats for its VEC channels each) -> stats[s*C + c] += block total
-template <typename T, int NS>
-__device__ __forceinline__ void block_channel_reduce(float (*sums)[ET<T>::VEC], const RowMap<T>& m, int C, double* const* dst) {
+template <typename T, int NS, typename OUT = double>
+__device__ __forceinline__ void block_channel_reduce(float (*sums)[ET<T>::VEC], const RowMap<T>& m, int C, OUT* const* dst) {
     constexpr int VEC = ET<T>::VEC;
     __shared__ float red[256 * NS * VEC];
 #pragma unroll
@@ -34,7 +34,7 @@ __device__ __forceinline__ void block_channel_reduce(float (*sums)[ET<T>::VEC], 
         const int cv = c / VEC, j = c - cv * VEC;
         float tot = 0.f;
         for (int r = 0; r < m.rpi; ++r) tot += red[((r * m.cvs + cv) * NS + s) * VEC + j];
-        atomicAdd(&dst[s][c], (double)tot);
+        atomicAdd(&dst[s][c], (OUT)tot);
     }
 }
 
@@ -42,8 +42,8 @@ __device__ __forceinline__ void block_channel_reduce(float (*sums)[ET<T>::VEC], 
 // two): lanes of a wave that own the same channels are folded with shuffles first, then the NT/64 waves through
 // LDS, one sum at a time.  Big workgroups keep the number of workgroups -- and with it the number of double
 // atomics that pile up on the same few cache lines at the end of the kernel -- small.
-template <typename T, int NS, int NT>
-__device__ __forceinline__ void wide_channel_reduce(float (*sums)[ET<T>::VEC], const RowMap<T, NT>& m, int C, double* const* dst) {
+template <typename T, int NS, int NT, typename OUT = double>
+__device__ __forceinline__ void wide_channel_reduce(float (*sums)[ET<T>::VEC], const RowMap<T, NT>& m, int C, OUT* const* dst) {
     constexpr int VEC = ET<T>::VEC;
     constexpr int NW = NT / 64;
     __shared__ float red[NW * 64 * VEC];
@@ -68,7 +68,7 @@ __device__ __forceinline__ void wide_channel_reduce(float (*sums)[ET<T>::VEC], c
                 float tot = 0.f;
 #pragma unroll
                 for (int w = 0; w < NW; ++w) tot += red[(w * 64 + cv) * VEC + j];
-                atomicAdd(&dst[s][c], (double)tot);
+                atomicAdd(&dst[s][c], (OUT)tot);
             }
         }
     }
@@ -222,7 +222,8 @@ struct BlockOutBwdArgs {
     const float* meanr; const float* rstdr; const float* gammar;
     double* stats2; double* statsr;
     void* dO; void* dR; void* g;
-    double* dbias_o; double* dbias_r;
+    float* dbias_o; float* dbias_r;          // float32 sums (atomics), zeroed by the caller
+    float* dgamma2; float* dbeta2; float* dgammar; float* dbetar;   // optional: BatchNorm parameter gradients from stats2 / statsr
     size_t rows; int C; uint32_t seed, thr; float keep_scale; double count; int training;
 };
 
@@ -397,9 +398,18 @@ __global__ __launch_bounds__(NT) void block_out_bwd_apply_kernel(BlockOutBwdArgs
                 if (row + i * rstep < a.rows) consume(row + i * rstep, p[i]);
         }
     }
-    double* dst[2] = {a.dbias_o, HAS_R ? a.dbias_r : nullptr};
-    if constexpr (NT == 256) block_channel_reduce<T, 2>(sums, m, a.C, dst);
-    else wide_channel_reduce<T, HAS_R ? 2 : 1, NT>(sums, m, a.C, dst);
+    float* dst[2] = {a.dbias_o, HAS_R ? a.dbias_r : nullptr};
+    if constexpr (NT == 256) block_channel_reduce<T, 2, float>(sums, m, a.C, dst);
+    else wide_channel_reduce<T, HAS_R ? 2 : 1, NT, float>(sums, m, a.C, dst);
+    // the sums of the reduce pass are the BatchNorm parameter gradients: dbeta = sum g, dgamma = sum g*xhat
+    if (blockIdx.x == 0) {
+        for (int c = threadIdx.x; c < a.C; c += NT) {
+            if (a.dbeta2) a.dbeta2[c] = (float)a.stats2[c];
+            if (a.dgamma2) a.dgamma2[c] = (float)a.stats2[a.C + c];
+            if (HAS_R && a.dbetar) a.dbetar[c] = (float)a.statsr[c];
+            if (HAS_R && a.dgammar) a.dgammar[c] = (float)a.statsr[a.C + c];
+        }
+    }
 }
 
 // The reduce pass reads the conv residual whenever there is one; the apply pass only when it writes dR.
@@ -430,7 +440,8 @@ extern "C" int stgcn_block_out_bwd(int dtype, int pass, const void* dout, const 
                                    const float* mean2, const float* rstd2, const float* gamma2,
                                    const float* meanr, const float* rstdr, const float* gammar,
                                    double* stats2, double* statsr, void* dO, void* dR, void* g,
-                                   double* dbias_o, double* dbias_r,
+                                   float* dbias_o, float* dbias_r,
+                                   float* dgamma2, float* dbeta2, float* dgammar, float* dbetar,
                                    size_t rows, int C, float drop_p, uint32_t seed, double count, int training, void* stream) {
     if ((!dout && !dpool) || (!out && !relu_mask) || !o || !mean2 || !rstd2 || !stats2) return STGCN_ERR_ARG;
     if (dpool && rows_per_sample == 0) return STGCN_ERR_ARG;
@@ -439,6 +450,7 @@ extern "C" int stgcn_block_out_bwd(int dtype, int pass, const void* dout, const 
     a.dout = dout; a.dpool = dpool; a.rows_per_sample = rows_per_sample; a.out = out; a.mask = (const uint16_t*)relu_mask; a.o = o; a.r = r; a.mean2 = mean2; a.rstd2 = rstd2; a.gamma2 = gamma2;
     a.meanr = meanr; a.rstdr = rstdr; a.gammar = gammar; a.stats2 = stats2; a.statsr = statsr;
     a.dO = dO; a.dR = dR; a.g = g; a.dbias_o = dbias_o; a.dbias_r = dbias_r;
+    a.dgamma2 = dgamma2; a.dbeta2 = dbeta2; a.dgammar = dgammar; a.dbetar = dbetar;
     a.rows = rows; a.C = C; a.seed = seed; a.thr = drop_thr(drop_p); a.keep_scale = 1.f / (1.f - drop_p);
     a.count = count; a.training = training;
     if (pass == 1) {
@@ -460,11 +472,18 @@ extern "C" int stgcn_block_out_bwd(int dtype, int pass, const void* dout, const 
 struct BnBwdArgs {
     const void* g; const void* y; void* dy; const float* gamma; const float* mean; const float* rstd;
     const double* stats; double count; size_t rows; int C; int training;
+    float* dgamma; float* dbeta;             // optional: dbeta = stats[0..C), dgamma = stats[C..2C) as float32
 };
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a) {
     constexpr int VEC = ET<T>::VEC;
     RowMap<T> m(a.C);
+    if (blockIdx.x == 0 && a.stats) {
+        for (int c = threadIdx.x; c < a.C; c += 256) {
+            if (a.dbeta) a.dbeta[c] = (float)a.stats[c];
+            if (a.dgamma) a.dgamma[c] = (float)a.stats[a.C + c];
+        }
+    }
     if (!m.active) return;
     float mu[VEC], rs[VEC], kk[VEC], m1[VEC], m2[VEC];
 #pragma unroll
@@ -486,11 +505,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a) {
 }
 extern "C" int stgcn_bn_bwd_apply(int dtype, const void* g, const void* y, void* dy, const float* gamma,
                                   const float* mean, const float* rstd, const double* stats, double count,
-                                  size_t rows, int C, int training, void* stream) {
+                                  float* dgamma, float* dbeta, size_t rows, int C, int training, void* stream) {
     if (!g || !y || !dy || !gamma || !mean || !rstd || (training && !stats)) return STGCN_ERR_ARG;
     BnBwdArgs a;
     a.g = g; a.y = y; a.dy = dy; a.gamma = gamma; a.mean = mean; a.rstd = rstd; a.stats = stats; a.count = count;
-    a.rows = rows; a.C = C; a.training = training;
+    a.rows = rows; a.C = C; a.training = training; a.dgamma = dgamma; a.dbeta = dbeta;
     if (dtype == STGCN_BF16) {
         if (!ew_ok<bf16>(C)) return STGCN_ERR_ARG;
         hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16>, dim3(ew_grid(rows, ew_rpi<bf16>(C))), dim3(256), 0, (hipStream_t)stream, a);

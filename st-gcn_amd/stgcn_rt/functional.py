@@ -171,11 +171,9 @@ class StGcnBlockFn(torch.autograd.Function):
         # identity residual: its gradient is the masked incoming gradient.  With a stored dout and the forward's bit
         # mask, the graph-conv dX kernel masks dout itself and nothing is written for it.
         mask_in_dx = kind == "identity" and dout is not None and dpool is None and ctx.relu_mask is not None
-        dO, dR, g, stats2, statsr, dbo, dbr = P.block_out_bwd(
+        dO, dR, g, stats2, statsr, dbt, dbr_f, (dg2, db2, dgr, dbetar) = P.block_out_bwd(
             dout, out, o, r_, bn2, f32(g2), bnr, f32(gr) if kind == "conv" else None, kind == "identity" and not mask_in_dx,
-            p, seed, training, dpool=dpool, relu_mask=ctx.relu_mask)
-        dg2, db2 = P.stats_to_grads(stats2, Cout)
-        dbt = dbo.float()
+            p, seed, training, dpool=dpool, relu_mask=ctx.relu_mask, want_bn_grads=True)
 
         # temporal conv: weight grad (input = relu(bn1(y)) recomputed in the prologue), then data grad fused with
         # the ReLU mask and the BN1-backward sums
@@ -183,18 +181,15 @@ class StGcnBlockFn(torch.autograd.Function):
         stats1 = P.stats_alloc((2 * Cout,), dev)
         gh = P.conv_rows(dO, packs[1][1], Cout, T, epilogue=L.EPI_RELU_BWD, aux=y, ep=(bn1.scale, bn1.shift, bn1.mean, bn1.rstd),
                          stats=stats1, ntaps=kt, stride=stride, pad=pad, transposed=True)
-        dg1, db1 = P.stats_to_grads(stats1, Cout)
         if CAPTURE is not None:
             pre = y.float() * bn1.scale[None, :, None, None] + bn1.shift[None, :, None, None]
             near = pre.abs() < 1e-4          # decided by the kernel's own fma there: read it off its output
             CAPTURE.append(dict(h_mask=torch.where(near, gh != 0, pre > 0), out_mask=(out > 0)))
-        dy = P.bn_bwd_apply(gh, y, f32(g1), bn1, stats1, training, out=gh)
+        dy, dg1, db1 = P.bn_bwd_apply(gh, y, f32(g1), bn1, stats1, training, out=gh, want_grads=True)
 
         add = g
-        dWr = dbr_f = dgr = dbetar = None
+        dWr = None
         if kind == "conv":
-            dgr, dbetar = P.stats_to_grads(statsr, Cout)
-            dbr_f = dbr.float()
             dWr = P.conv_wgrad(x, dR, 1, stride, 0)
             add = P.conv_rows(dR, packs[2][1], cin_p, T, ntaps=1, stride=stride, pad=0, transposed=True)
 

@@ -29,8 +29,8 @@ _SIGS = {
     "stgcn_stats_to_grads": [_vp, _vp, _vp, _i, _vp],
     "stgcn_block_out_fwd": [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _f, _u32, _vp],
     "stgcn_block_out_bwd": [_i, _i, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
-                            _vp, _vp, _sz, _i, _f, _u32, _d, _i, _vp],
-    "stgcn_bn_bwd_apply": [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _d, _sz, _i, _i, _vp],
+                            _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _f, _u32, _d, _i, _vp],
+    "stgcn_bn_bwd_apply": [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _d, _vp, _vp, _sz, _i, _i, _vp],
     "stgcn_augment": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "stgcn_data_bn_stats": [_vp, _vp, _i, _i, _i, _i, _i, _vp],
     "stgcn_data_bn_apply": [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],

@@ -303,18 +303,25 @@ def block_out_fwd(o, res, bn2, bnr, drop_p, seed, want_mask=False):
     return (out, mask) if want_mask else out
 
 
-def block_out_bwd(dout, out, o, r, bn2, gamma2, bnr, gammar, want_g, drop_p, seed, training, dpool=None, relu_mask=None):
-    """-> dO, dR (or None), g (or None), stats2 [2,C] (sum gd, sum gd*ohat), statsr, dbias_o, dbias_r (double).
+def block_out_bwd(dout, out, o, r, bn2, gamma2, bnr, gammar, want_g, drop_p, seed, training, dpool=None, relu_mask=None,
+                  want_bn_grads=False):
+    """-> dO, dR (or None), g (or None), stats2 [2,C] (sum gd, sum gd*ohat), statsr, dbias_o, dbias_r (float32);
+    with want_bn_grads additionally (dgamma2, dbeta2, dgammar, dbetar) as float32, written by the apply pass.
     The incoming gradient is dout (stored tensor) and/or dpool [B,C] float32, constant over (t,v).  The ReLU
     decisions are read from relu_mask (as written by block_out_fwd) when given, else from out."""
     B, Cc, T, V = o.shape
     rows = B * T * V
-    acc = stats_alloc((6, Cc), o.device)
-    stats2, statsr, dbo, dbr = acc[0:2], acc[2:4], acc[4], acc[5]
+    acc = stats_alloc((5, Cc), o.device)
+    stats2, statsr = acc[0:2], acc[2:4]
+    dbf = acc[4].view(torch.float32)                      # zeroed: two float32 sums in the space of one double row
+    dbo, dbr = dbf[:Cc], dbf[Cc:]
     has_r = r is not None
+    bng = torch.empty((4, Cc), dtype=torch.float32, device=o.device) if want_bn_grads else None
     args = [L.dtype_code(o.dtype), 0, L.ptr(dout), L.ptr(dpool), T * V, L.ptr(out) if relu_mask is None else None, L.ptr(relu_mask), L.ptr(o), L.ptr(r), L.ptr(bn2.mean), L.ptr(bn2.rstd), L.ptr(gamma2),
             L.ptr(bnr.mean) if has_r else None, L.ptr(bnr.rstd) if has_r else None, L.ptr(gammar) if has_r else None,
             L.ptr(stats2), L.ptr(statsr) if has_r else None, None, None, None, L.ptr(dbo), L.ptr(dbr) if has_r else None,
+            L.ptr(bng[0]) if want_bn_grads else None, L.ptr(bng[1]) if want_bn_grads else None,
+            L.ptr(bng[2]) if want_bn_grads and has_r else None, L.ptr(bng[3]) if want_bn_grads and has_r else None,
             rows, Cc, float(drop_p), int(seed) & 0xFFFFFFFF, float(rows), 1 if training else 0, L.stream_ptr()]
     _launch((str(o.dtype), 0, rows, Cc, has_r), "stgcn_block_out_bwd", *args)
     dO = new_act(B, Cc, T, V, o.dtype, o.device)
@@ -323,16 +330,23 @@ def block_out_bwd(dout, out, o, r, bn2, gamma2, bnr, gammar, want_g, drop_p, see
     args[1] = 1
     args[17], args[18], args[19] = L.ptr(dO), L.ptr(dR), L.ptr(g)
     _launch((str(o.dtype), 1, rows, Cc, has_r, want_g), "stgcn_block_out_bwd", *args)
-    return dO, dR, g, stats2, (statsr if has_r else None), dbo, (dbr if has_r else None)
+    res = (dO, dR, g, stats2, (statsr if has_r else None), dbo, (dbr if has_r else None))
+    if want_bn_grads:
+        res = res + ((bng[0], bng[1], bng[2] if has_r else None, bng[3] if has_r else None),)
+    return res
 
 
-def bn_bwd_apply(g, y, gamma, bn, stats, training, out=None):
+def bn_bwd_apply(g, y, gamma, bn, stats, training, out=None, want_grads=False):
+    """-> dy; with want_grads (dy, dgamma, dbeta): the parameter gradients are the sums in `stats`, converted to
+    float32 by the same launch."""
     B, Cc, T, V = y.shape
     if out is None:
         out = new_act(B, Cc, T, V, y.dtype, y.device)
+    pg = torch.empty((2, Cc), dtype=torch.float32, device=y.device) if want_grads else None
     _launch((str(y.dtype), B * T * V, Cc), "stgcn_bn_bwd_apply", L.dtype_code(y.dtype), L.ptr(g), L.ptr(y), L.ptr(out), L.ptr(gamma), L.ptr(bn.mean), L.ptr(bn.rstd),
-           L.ptr(stats), float(B * T * V), B * T * V, Cc, 1 if training else 0, L.stream_ptr())
-    return out
+           L.ptr(stats), float(B * T * V), L.ptr(pg[0]) if want_grads else None, L.ptr(pg[1]) if want_grads else None,
+           B * T * V, Cc, 1 if training else 0, L.stream_ptr())
+    return (out, pg[0], pg[1]) if want_grads else out
 
 
 def sgd_step(params, grads, mom, lr, momentum, weight_decay, nesterov, first_step, grad_scale=1.0):

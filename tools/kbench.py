@@ -84,16 +84,17 @@ def make(case, dtype):
         bnr = R.bn_finalize(torch.rand((2, Cc), dtype=torch.float64, device=DEV) * rows, rows, mk(), mk(), torch.zeros(Cc, device=DEV), torch.ones(Cc, device=DEV), True)
         g2, gr = mk(), mk()
         mask = torch.randint(-32768, 32767, (rows * Cc * o.element_size() // 16,), dtype=torch.int16, device=DEV)
-        acc = torch.zeros((6, Cc), dtype=torch.float64, device=DEV)
+        acc = torch.zeros((4, Cc), dtype=torch.float64, device=DEV)
+        dbf = torch.zeros((2, Cc), dtype=torch.float32, device=DEV)
         dO, dR, g = torch.empty_like(o), torch.empty_like(o), torch.empty_like(o)
         ps = 0 if name.startswith("bob0") else 1
         args = [L.dtype_code(o.dtype), ps, L.ptr(dout), None, Tt * V, None, L.ptr(mask), L.ptr(o), L.ptr(r), L.ptr(bn2.mean), L.ptr(bn2.rstd), L.ptr(g2),
                 L.ptr(bnr.mean) if has_r else None, L.ptr(bnr.rstd) if has_r else None, L.ptr(gr) if has_r else None,
                 L.ptr(acc[0:2]), L.ptr(acc[2:4]) if has_r else None,
                 L.ptr(dO) if ps else None, L.ptr(dR) if (ps and has_r) else None, L.ptr(g) if (ps and not has_r) else None,
-                L.ptr(acc[4]), L.ptr(acc[5]) if has_r else None,
+                L.ptr(dbf[0]), L.ptr(dbf[1]) if has_r else None, None, None, None, None,
                 rows, Cc, 0.5, 1234, float(rows), 1, L.stream_ptr()]
-        keepalive = (o, dout, r, mask, acc, dO, dR, g, bn2, bnr, g2, gr)
+        keepalive = (o, dout, r, mask, acc, dbf, dO, dR, g, bn2, bnr, g2, gr)
         return lambda: (L.call("stgcn_block_out_bwd", *args), keepalive)[0]
     if name == "bnbwd":                                  # bn_bwd_apply
         Cc, Tt = Cin, Tin

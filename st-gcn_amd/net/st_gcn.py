@@ -18,7 +18,7 @@ import torch.nn as nn
 from net.utils.graph import Graph
 from net.utils.tgcn import ConvTemporalGraphical
 from stgcn_rt import ops as P
-from stgcn_rt.functional import DataBnFn, HeadFn, StGcnBlockFn
+from stgcn_rt.functional import DataBnFn, EdgeImportanceFn, HeadFn, StGcnBlockFn
 
 
 def _default_dtype():
@@ -87,10 +87,14 @@ class Model(nn.Module):
         packs = self._packed_weights(dtype, h.device)
         counters = [bn.num_batches_tracked] if self.training else None
         last = len(self.st_gcn_networks) - 1
-        for i, (gcn, importance) in enumerate(zip(self.st_gcn_networks, self.edge_importance)):
+        if isinstance(self.edge_importance, nn.ParameterList):
+            a_eff = EdgeImportanceFn.apply(self.A, *self.edge_importance)       # A * importance, all blocks at once
+        else:
+            a_eff = [self.A * importance for importance in self.edge_importance]
+        for i, gcn in enumerate(self.st_gcn_networks):
             # global average pool over (T, V) fused into the last block (st_gcn.py:85 of the reference)
             want_pool = pool_last and i == last
-            h, pooled = gcn._run(h, self.A * importance, want_pool, packs=packs[i], counters=counters)
+            h, pooled = gcn._run(h, a_eff[i], want_pool, packs=packs[i], counters=counters)
             if want_pool:
                 h = pooled
         if counters:

@@ -206,6 +206,34 @@ class StGcnBlockFn(torch.autograd.Function):
                 None, None, None, None, None, None, None, None)
 
 
+class EdgeImportanceFn(torch.autograd.Function):
+    """A * importance_i for every block at once (net/st_gcn.py:81-82 of the reference multiplies per block):
+    two launches forward (stack, multiply) and two backward instead of one multiply per block each way.
+    Returns one [K,V,V] float32 tensor per block."""
+
+    @staticmethod
+    def forward(ctx, A, *importances):
+        imp = torch.stack([p.detach().float() for p in importances])
+        ctx.save_for_backward(A)
+        return tuple((A.detach().float().unsqueeze(0) * imp).unbind(0))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        (A,) = ctx.saved_tensors
+        if all(g is None for g in grads):
+            return (None,) * (1 + len(grads))
+        zero = None
+        gl = []
+        for g in grads:
+            if g is None:
+                if zero is None:
+                    zero = torch.zeros_like(A, dtype=torch.float32)
+                g = zero
+            gl.append(g.float())
+        d = torch.stack(gl) * A.detach().float().unsqueeze(0)
+        return (None,) + tuple(d.unbind(0))
+
+
 class DataBnFn(torch.autograd.Function):
     """x [N,C,T,V,M] float32 -> channels-last activation [N*M, Cp, T, V] after BatchNorm1d(V*C)."""
 

@@ -219,11 +219,12 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(ConvWgradArgs a) {
 }
 
 // dW[co][ci][tap] = sum_part slab[part][tap][co][ci]   (torch conv weight layout [Cout][Cin][ntaps][1])
-__global__ void conv_wgrad_reduce_kernel(const float* slab, float* dW, int nparts, int ntaps, int Cout, int Cin) {
+__global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float* slab, float* dW, int nparts, int ntaps, int Cout, int Cin) {
+    __shared__ float red[256];
     const size_t n = (size_t)ntaps * Cout * Cin;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        float s = 0.f;
-        for (int p = 0; p < nparts; ++p) s += slab[(size_t)p * n + i];
+    const size_t i = (size_t)blockIdx.x * 64 + (threadIdx.x & 63);
+    const float s = slab_sum64(slab, nparts, n, i, red);
+    if (threadIdx.x < 64 && i < n) {
         const int ci = (int)(i % Cin);
         const size_t rest = i / Cin;
         const int co = (int)(rest % Cout);
@@ -542,8 +543,7 @@ static int conv_wgrad_ring_try(const void* in, const void* dout, float* dW, cons
     }
     if (hipGetLastError() != hipSuccess) return STGCN_ERR_LAUNCH;
     const size_t n = (size_t)ntaps * Cout * Cin;
-    const int left = fold_parts(a.slab, nwg, n, stream);
-    hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a.slab, dW, left, ntaps, Cout, Cin);
+    hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3(slab_sum_grid(n)), dim3(256), 0, stream, a.slab, dW, nwg, ntaps, Cout, Cin);
     return hipGetLastError() == hipSuccess ? STGCN_OK : STGCN_ERR_LAUNCH;
 }
 
@@ -586,9 +586,8 @@ static int conv_wgrad_run(ConvWgradArgs& a, float* dW, size_t ws_bytes, hipStrea
     rc = hipGetLastError() == hipSuccess ? STGCN_OK : STGCN_ERR_LAUNCH;
     if (rc) return rc;
     const size_t n = (size_t)a.ntaps * a.Cout * a.Cin;
-    const int left = fold_parts(a.slab, nseg * wave_parts, n, stream);
-    hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
-                       a.slab, dW, left, a.ntaps, a.Cout, a.Cin);
+    hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3(slab_sum_grid(n)), dim3(256), 0, stream,
+                       a.slab, dW, nseg * wave_parts, a.ntaps, a.Cout, a.Cin);
     return hipGetLastError() == hipSuccess ? STGCN_OK : STGCN_ERR_LAUNCH;
 }
 

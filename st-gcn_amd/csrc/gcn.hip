@@ -546,22 +546,22 @@ __global__ __launch_bounds__(256, 2) void gcn_agrad_kernel(GcnAgradArgs a) {
 }
 
 // sum of the partials [nparts][n1 + n2] into out1[n1] and out2[n2] (out2 may be null)
-__global__ void sum_parts2_kernel(const float* slab, float* out1, size_t n1, float* out2, size_t n2, int nparts) {
+__global__ __launch_bounds__(256) void sum_parts2_kernel(const float* slab, float* out1, size_t n1, float* out2, size_t n2, int nparts) {
+    __shared__ float red[256];
     const size_t n = n1 + n2;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        float s = 0.f;
-        for (int p = 0; p < nparts; ++p) s += slab[(size_t)p * n + i];
+    const size_t i = (size_t)blockIdx.x * 64 + (threadIdx.x & 63);
+    const float s = slab_sum64(slab, nparts, n, i, red);
+    if (threadIdx.x < 64 && i < n) {
         if (i < n1) out1[i] = s;
         else if (out2) out2[i - n1] = s;
     }
 }
 
-__global__ void sum_parts_kernel(const float* slab, float* out, int nparts, size_t n) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        float s = 0.f;
-        for (int p = 0; p < nparts; ++p) s += slab[(size_t)p * n + i];
-        out[i] = s;
-    }
+__global__ __launch_bounds__(256) void sum_parts_kernel(const float* slab, float* out, int nparts, size_t n) {
+    __shared__ float red[256];
+    const size_t i = (size_t)blockIdx.x * 64 + (threadIdx.x & 63);
+    const float s = slab_sum64(slab, nparts, n, i, red);
+    if (threadIdx.x < 64 && i < n) out[i] = s;
 }
 
 template <typename T, int NA>
@@ -602,8 +602,7 @@ static int gcn_agrad_run(GcnAgradArgs& a, float* dA, size_t ws_bytes, hipStream_
         default: rc = gcn_agrad_launch<T, 0>(a, grid, lds, stream); break;
     }
     if (rc != STGCN_OK) return rc;
-    const int left = fold_parts(a.slab, gx * gy, n, stream);
-    hipLaunchKernelGGL(sum_parts_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a.slab, dA, left, n);
+    hipLaunchKernelGGL(sum_parts_kernel, dim3(slab_sum_grid(n)), dim3(256), 0, stream, a.slab, dA, gx * gy, n);
     return hipGetLastError() == hipSuccess ? STGCN_OK : STGCN_ERR_LAUNCH;
 }
 
@@ -1036,8 +1035,7 @@ static int gcn_wgrad_wide_try(const void* x, const void* dy, const float* adj, f
     if (hipGetLastError() != hipSuccess) return STGCN_ERR_LAUNCH;
     // one reduction over the combined partials, written to the two outputs
     const size_t n = nW + nB;
-    const int left = fold_parts(a.slabW, gx, n, stream);
-    hipLaunchKernelGGL(sum_parts2_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a.slabW, dW, nW, db, nB, left);
+    hipLaunchKernelGGL(sum_parts2_kernel, dim3(slab_sum_grid(n)), dim3(256), 0, stream, a.slabW, dW, nW, db, nB, gx);
     return hipGetLastError() == hipSuccess ? STGCN_OK : STGCN_ERR_LAUNCH;
 }
 
@@ -1067,11 +1065,9 @@ static int gcn_wgrad_run(GcnWgradArgs& a, float* dW, float* db, size_t ws_bytes,
     if (!set) { if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return STGCN_ERR_LAUNCH; set = true; }
     hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)ncot, (unsigned)ncig), dim3(256), lds, stream, a);
     if (hipGetLastError() != hipSuccess) return STGCN_ERR_LAUNCH;
-    const int leftW = fold_parts(a.slabW, gx, nW, stream);
-    hipLaunchKernelGGL(sum_parts_kernel, dim3((unsigned)((nW + 255) / 256)), dim3(256), 0, stream, a.slabW, dW, leftW, nW);
+    hipLaunchKernelGGL(sum_parts_kernel, dim3(slab_sum_grid(nW)), dim3(256), 0, stream, a.slabW, dW, gx, nW);
     if (db) {
-        const int leftB = fold_parts(a.slabB, gx, nB, stream);
-        hipLaunchKernelGGL(sum_parts_kernel, dim3((unsigned)((nB + 255) / 256)), dim3(256), 0, stream, a.slabB, db, leftB, nB);
+        hipLaunchKernelGGL(sum_parts_kernel, dim3(slab_sum_grid(nB)), dim3(256), 0, stream, a.slabB, db, gx, nB);
     }
     return hipGetLastError() == hipSuccess ? STGCN_OK : STGCN_ERR_LAUNCH;
 }

@@ -135,22 +135,28 @@ __device__ __forceinline__ i32x4 zero16() { i32x4 z = {0, 0, 0, 0}; return z; }
 
 static inline int ceil_div_i(int a, int b) { return (a + b - 1) / b; }
 
-// Two-stage fixed-order reduction of a partial-sum slab [nparts][n] (f32):
-//   stage 1 (fold_parts_kernel, grid (ceil(n/256), S)): part `s` <- sum of parts s, s+S, s+2S, ...   (in place)
-//   stage 2: the caller's final kernel sums the first S parts.
-// Every element is summed in the same order every run, so results are bitwise reproducible.
-__global__ static void fold_parts_kernel(float* slab, int nparts, size_t n, int S) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int s = blockIdx.y;
-    if (i >= n) return;
-    float acc = 0.f;
-    for (int p = s; p < nparts; p += S) acc += slab[(size_t)p * n + i];
-    slab[(size_t)s * n + i] = acc;
+// Fixed-order reduction of a partial-sum slab [nparts][n] (f32) in one launch.  A workgroup of 256 threads is
+// 64 consecutive elements x 4 part groups: thread (o = tid & 63, g = tid >> 6) adds parts g, g+4, g+8, ... of element
+// blockIdx.x*64 + o (four loads in flight), the four group sums are added in the order 0..3 through LDS.  Every
+// element is summed in the same order every run, so results are bitwise reproducible.  The total is returned to the
+// threads with g == 0; `red` is 256 floats of LDS.  Launch with slab_sum_grid(n) workgroups of 256 threads.
+__device__ __forceinline__ float slab_sum64(const float* slab, int nparts, size_t n, size_t i, float* red) {
+    const int g = threadIdx.x >> 6;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (i < n) {
+        int p = g;
+        for (; p + 12 < nparts; p += 16) {
+            a0 += slab[(size_t)p * n + i];
+            a1 += slab[(size_t)(p + 4) * n + i];
+            a2 += slab[(size_t)(p + 8) * n + i];
+            a3 += slab[(size_t)(p + 12) * n + i];
+        }
+        for (; p < nparts; p += 4) a0 += slab[(size_t)p * n + i];
+    }
+    red[threadIdx.x] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    float tot = 0.f;
+    if (g == 0) tot = (red[threadIdx.x] + red[threadIdx.x + 64]) + (red[threadIdx.x + 128] + red[threadIdx.x + 192]);
+    return tot;
 }
-// returns the number of parts left to sum (<= 32)
-static inline int fold_parts(float* slab, int nparts, size_t n, hipStream_t stream) {
-    if (nparts <= 32) return nparts;
-    const int S = 32;
-    hipLaunchKernelGGL(fold_parts_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)S), dim3(256), 0, stream, slab, nparts, n, S);
-    return S;
-}
+static inline unsigned slab_sum_grid(size_t n) { return (unsigned)((n + 63) / 64); }

@@ -564,6 +564,19 @@ __global__ __launch_bounds__(256) void sum_parts_kernel(const float* slab, float
     if (threadIdx.x < 64 && i < n) out[i] = s;
 }
 
+// Few elements, many parts (dA: 3*V*V sums of up to 512 partials): one wave per element, lane l adds parts
+// l, l+64, ...; the lanes are then folded with a fixed butterfly, so the order of additions never changes.
+__global__ __launch_bounds__(256) void sum_parts_wave_kernel(const float* slab, float* out, int nparts, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int p = lane; p < nparts; p += 64) s += slab[(size_t)p * n + i];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d);
+    if (lane == 0) out[i] = s;
+}
+
 template <typename T, int NA>
 static int gcn_agrad_launch(GcnAgradArgs& a, dim3 grid, size_t lds, hipStream_t stream) {
     auto kern = gcn_agrad_kernel<T, NA>;
@@ -602,7 +615,7 @@ static int gcn_agrad_run(GcnAgradArgs& a, float* dA, size_t ws_bytes, hipStream_
         default: rc = gcn_agrad_launch<T, 0>(a, grid, lds, stream); break;
     }
     if (rc != STGCN_OK) return rc;
-    hipLaunchKernelGGL(sum_parts_kernel, dim3(slab_sum_grid(n)), dim3(256), 0, stream, a.slab, dA, gx * gy, n);
+    hipLaunchKernelGGL(sum_parts_wave_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, a.slab, dA, gx * gy, n);
     return hipGetLastError() == hipSuccess ? STGCN_OK : STGCN_ERR_LAUNCH;
 }
 

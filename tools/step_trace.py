@@ -1,0 +1,23 @@
+"""Per-step launch statistics from a rocprofv3 --kernel-trace CSV of bench.py: launches, busy time, gaps, and the
+kernels shorter than 20 us.  usage: step_trace.py kernel_trace.csv"""
+import collections
+import csv
+import sys
+
+rows = list(csv.DictReader(open(sys.argv[1])))
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+idx = [i for i, r in enumerate(rows) if "sgd_kernel" in r["Kernel_Name"]]
+step = rows[idx[-2] + 1:idx[-1] + 1]
+t0, t1 = int(step[0]["Start_Timestamp"]), int(step[-1]["End_Timestamp"])
+dur = lambda r: int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+print("step span %.3f ms, busy %.3f ms, launches %d" % ((t1 - t0) / 1e6, sum(map(dur, step)) / 1e6, len(step)))
+gaps = [int(step[i + 1]["Start_Timestamp"]) - int(step[i]["End_Timestamp"]) for i in range(len(step) - 1)]
+print("gaps: %.3f ms total, max %.1f us" % (sum(g for g in gaps if g > 0) / 1e6, max(gaps) / 1e3))
+agg = collections.defaultdict(lambda: [0, 0])
+for r in step:
+    agg[r["Kernel_Name"][:80]][0] += 1
+    agg[r["Kernel_Name"][:80]][1] += dur(r)
+small = [(k, v) for k, v in agg.items() if v[1] / v[0] < 20000]
+print("kernels under 20 us: %d launches, %.3f ms" % (sum(v[0] for _, v in small), sum(v[1] for _, v in small) / 1e6))
+for k, v in sorted(small, key=lambda kv: -kv[1][1])[:16]:
+    print("  %3d x %6.1f us  %s" % (v[0], v[1] / v[0] / 1e3, k))

@@ -288,3 +288,56 @@ def test_trainer_steps_match_oracle(net, dtype):
     print("worst parameter rel-L2 deviation after 3 steps:", worst, "losses", losses, ref_losses)
     assert worst[1] < (1e-4 if dtype == torch.float32 else 5e-2), worst
     assert int(rsd["data_bn.num_batches_tracked"]) == 3 and int(rsd["st_gcn_networks.4.residual.1.num_batches_tracked"]) == 3
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+def test_training_learns_a_separable_task(net, dtype):
+    """End to end: feeder-style augmentation on the GPU, Trainer steps (forward, cross-entropy, backward, SGD-nesterov)
+    -- on clips whose class is written into the motion of one joint, the loss has to fall and the fit to become exact.
+    Not a parity check; it guards against an update path that matches nothing in particular but still 'runs'."""
+    m, _ = net
+    from feeder import tools
+    from stgcn_rt import ops as P
+    from stgcn_rt.ddp import Trainer
+    from stgcn_rt.evaluate import evaluate
+    import random
+    torch.manual_seed(0)
+    N, T, W, V, M, ncls = 16, 40, 32, 25, 2, 4
+    rs = np.random.RandomState(0)
+    labels = np.arange(N) % ncls
+    x = 0.05 * rs.randn(N, 3, T, V, M).astype(np.float32)
+    tt = np.arange(T, dtype=np.float32)
+    for n in range(N):                                   # class c: joint 3 oscillates with frequency (c+1)
+        x[n, 0, :, 3, :] += np.sin(2 * np.pi * (labels[n] + 1) * tt / T)[:, None]
+        x[n, 1, :, 7, :] += np.cos(2 * np.pi * (labels[n] + 1) * tt / T)[:, None]
+    xd = torch.from_numpy(x).to(DEV)
+    yd = torch.from_numpy(labels).long().to(DEV)
+    model = m.Model(3, ncls, dict(layout="ntu-rgb+d", strategy="spatial"), True, dropout=0.0, compute_dtype=dtype).to(DEV)
+
+    def weights_init(mod):                               # processor/recognition.py:21-33
+        cn = mod.__class__.__name__
+        if cn.find("Conv1d") != -1 or cn.find("Conv2d") != -1:
+            mod.weight.data.normal_(0.0, 0.02)
+            if mod.bias is not None:
+                mod.bias.data.fill_(0)
+        elif cn.find("BatchNorm") != -1:
+            mod.weight.data.normal_(1.0, 0.02)
+            mod.bias.data.fill_(0)
+    model.apply(weights_init)
+    model.train()
+    tr = Trainer(model, lr=0.01, momentum=0.9, weight_decay=1e-4, nesterov=True)
+    losses = []
+    for it in range(60):
+        shifts = [tools.choose_shift(T, W, rng=random.Random(100 * it + n)) for n in range(N)]
+        params = [tools.move_params(W, angle_candidate=(-5., 0., 5.), scale_candidate=(0.95, 1.0, 1.05),
+                                    transform_candidate=(-0.05, 0.0, 0.05), rng=random.Random(it * 7 + n),
+                                    nprng=np.random.RandomState(it * 13 + n)) for n in range(N)]
+        move = tuple(np.stack([p[j] for p in params]) for j in range(4))
+        batch = P.augment_batch(xd, window=W, shift=shifts, move=move)
+        losses.append(float(tr.step(batch, yd).item()))
+    assert np.isfinite(losses).all()
+    print("losses", [round(v, 3) for v in losses[::6]], [round(v, 3) for v in losses[-5:]])
+    assert np.mean(losses[-5:]) < 0.35 * np.mean(losses[:3]), (losses[:3], losses[-5:])
+    res = evaluate(model, [(P.augment_batch(xd, window=W, shift=[4] * N), yd)], DEV, show_topk=(1,))
+    print("top1", res["topk"][1], "eval loss", res["mean_loss"])
+    assert res["topk"][1] >= 0.9, res["topk"]

@@ -41,7 +41,8 @@ struct ConvBigArgs {
 #define CB_INTERLEAVE(NR, NM) _Pragma("unroll") for (int i_ = 0; i_ < (NR) / 2; ++i_) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); } __builtin_amdgcn_sched_group_barrier(0x008, (NM) - (NR) / 2, 0);
 constexpr int CB_RS = 144;
 constexpr int CB_WIN_ROWS = 544;    // window capacity in rows
-constexpr int CB_BN_MAX = 128;      // widest column tile (sizes the weight buffers)
+constexpr int CB_WRS = 128;         // weight-tile row: one unpadded 128-byte chunk, its 16-byte slots XOR-swizzled
+constexpr int CB_NWB = 4;           // weight-tile buffers
 
 template <typename T, int WR, int WC, int MT, int NT, int EPI>
 __global__ __launch_bounds__(WR * WC * 64) void conv_big_kernel(ConvBigArgs a) {
@@ -55,14 +56,14 @@ __global__ __launch_bounds__(WR * WC * 64) void conv_big_kernel(ConvBigArgs a) {
     constexpr int NPF = (CB_WIN_ROWS + RPP - 1) / RPP;   // window pieces per thread
     constexpr int BN = WC * NT * 32;                     // column tile: 128 or 64 output channels
     constexpr int EPR = BN / VEC;                        // 16-byte pieces per output row of the tile
-    constexpr int WPT = BN * 8 / NTH;                    // weight-tile pieces per thread
+    constexpr int WPT = BN * 8 / NTH;                    // global->LDS loads (8 rows each) per wave per weight tile
     constexpr int ERP = NTH / EPR;                       // epilogue rows per pass
     constexpr int EPP = BM / ERP;                        // epilogue passes per tile
     constexpr int EG = EPP < 8 ? EPP : 8;                // passes whose auxiliary loads are issued together
     static_assert(BN == 128 || BN == 64, "column tile is 128 or 64");
     constexpr int SRS = BN * ES + 16;                  // epilogue staging row stride
     char* win = smem;
-    char* wbuf = smem + (size_t)CB_WIN_ROWS * CB_RS;     // 3 x [128][RS]
+    char* wbuf = smem + (size_t)CB_WIN_ROWS * CB_RS;     // CB_NWB x [BN][CB_WRS]
     const int ZOFF = a.zero_row * CB_RS;                 // byte offset of the all-zero row
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -139,33 +140,34 @@ __global__ __launch_bounds__(WR * WC * 64) void conv_big_kernel(ConvBigArgs a) {
             }
         }
     };
-    i32x4 wreg[WPT];
-    auto load_w = [&](int chunk, int tapi) {
-        const int tap = a.wk[tapi];
+    // Weight tiles (BN rows x one 128-byte chunk of Cin) go from global memory straight into LDS, 8 rows per wave
+    // instruction, without passing through registers.  Such a load writes the wave's 64 x 16 bytes contiguously, so
+    // rows are unpadded; to keep the fragment reads (32 rows, one 16-byte slot each) off each other's banks, slot q
+    // of row r holds the row's piece q ^ ((r >> 1) & 7) -- applied here on the global address of each lane.
+    // Columns past Cout repeat row Cout-1: their accumulators are never stored.
+    int wg_off[WPT];
 #pragma unroll
-        for (int i = 0; i < WPT; ++i) {
-            const int p = tid + NTH * i;
-            const int n = p >> 3, sg = p & 7;
-            const int co = co0 + n;
-            wreg[i] = zero16();
-            if (co < Cout) wreg[i] = *(const i32x4*)((const char*)a.w + (((size_t)tap * Cout + co) * Cin + chunk * CK + sg * VEC) * ES);
-        }
-    };
-    auto store_w = [&](int buf) {
+    for (int i = 0; i < WPT; ++i) {
+        const int row = (wave * WPT + i) * 8 + (lane >> 3);
+        const int piece = (lane & 7) ^ ((row >> 1) & 7);
+        wg_off[i] = (min(co0 + row, Cout - 1) * Cin + piece * VEC) * ES;
+    }
+    auto glds_w = [&](int chunk, int tapi, int buf) {
+        const char* src = (const char*)a.w + ((size_t)a.wk[tapi] * Cout * Cin + (size_t)chunk * CK) * ES;
 #pragma unroll
-        for (int i = 0; i < WPT; ++i) {
-            const int p = tid + NTH * i;
-            *(i32x4*)(wbuf + (size_t)buf * BN * CB_RS + (p >> 3) * CB_RS + (p & 7) * 16) = wreg[i];
-        }
+        for (int i = 0; i < WPT; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + wg_off[i]),
+                                             (__attribute__((address_space(3))) void*)(wbuf + (size_t)buf * BN * CB_WRS + (wave * WPT + i) * 8 * CB_WRS),
+                                             16, 0, 0);
     };
-
-    // Weight tiles cycle through three LDS buffers.  Tile g of the (chunk-major, then tap) sequence -- the same for
-    // every row tile of this workgroup, so it just wraps around -- is fetched to registers during step g-3, stored
-    // to buffer g % 3 during step g-2, published by the barrier that opens step g-1, and read during step g; its
-    // first fragments are already read at the end of step g-1.
+    // Tile g of the (chunk-major, then tap) sequence -- the same for every row tile of this workgroup, so it just
+    // wraps around -- lives in buffer g % 4.  Its loads are issued at the start of step g-3 (the buffer was last read
+    // during step g-4), waited for by each wave at the end of step g-2 (a counted wait that leaves the loads of step
+    // g-2 itself in flight), published by the barrier that opens step g-1, and read during step g; its first
+    // fragments are already read at the end of step g-1.
     int wi_chunk = 0, wi_tap = 0;                          // iterator of the next tile to fetch
-    auto load_w_next = [&]() {
-        load_w(wi_chunk, wi_tap);
+    auto glds_w_next = [&](int buf) {
+        glds_w(wi_chunk, wi_tap, buf);
         if (++wi_tap == ntaps) { wi_tap = 0; if (++wi_chunk == nchunks) wi_chunk = 0; }
     };
     int ti = blockIdx.x;
@@ -174,9 +176,10 @@ __global__ __launch_bounds__(WR * WC * 64) void conv_big_kernel(ConvBigArgs a) {
     tile_geo(ti, b, r0, r1, flo, wrows);
     if (ntaps > 0) {
         fetch_win(b, flo, wrows, 0);
-        load_w_next(); store_w(0);
-        load_w_next(); store_w(1);
-        load_w_next();
+        glds_w_next(0);
+        glds_w_next(1);
+        glds_w_next(2);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     int wcur = 0;                                          // buffer of the current step's weight tile
 
@@ -207,6 +210,8 @@ __global__ __launch_bounds__(WR * WC * 64) void conv_big_kernel(ConvBigArgs a) {
 
         if (ntaps > 0) {
             struct Frag { i32x4 af[MT]; i32x4 bf[NT]; };
+            // this lane's B-fragment row and (swizzled) slot of k-step 0; k-step s flips bits 5-6 of the offset
+            const int wb_off = ((wc * NT) * 32 + l31) * CB_WRS + ((h ^ ((l31 >> 1) & 7)) * 16);
             auto a_offsets = [&](int tapi, int (&aoff)[MT]) {
 #pragma unroll
                 for (int m = 0; m < MT; ++m) {
@@ -216,11 +221,11 @@ __global__ __launch_bounds__(WR * WC * 64) void conv_big_kernel(ConvBigArgs a) {
                 }
             };
             auto load_frag = [&](Frag& f, const int (&aoff)[MT], int wbi, int s) {
-                const char* wb = wbuf + (size_t)wbi * BN * CB_RS + ((wc * NT) * 32 + l31) * CB_RS + h * 16;
+                const char* wb = wbuf + wbi * (BN * CB_WRS) + (wb_off ^ (s * 32));
 #pragma unroll
                 for (int m = 0; m < MT; ++m) f.af[m] = *(const i32x4*)(win + aoff[m] + s * 32);
 #pragma unroll
-                for (int n = 0; n < NT; ++n) f.bf[n] = *(const i32x4*)(wb + n * 32 * CB_RS + s * 32);
+                for (int n = 0; n < NT; ++n) f.bf[n] = *(const i32x4*)(wb + n * 32 * CB_WRS);
             };
             auto mma_frag = [&](const Frag& f) {
 #pragma unroll
@@ -237,28 +242,25 @@ __global__ __launch_bounds__(WR * WC * 64) void conv_big_kernel(ConvBigArgs a) {
                 else if (tn < ntile_total) fetch_win(nb, nflo, nwrows, 0);
                 for (int tapi = 0; tapi < ntaps; ++tapi) {
                     lds_barrier();                         // weight tile of this step (and a new window) visible
-                    const int wnext = wcur == 2 ? 0 : wcur + 1;
-                    const int wstore = wnext == 2 ? 0 : wnext + 1;
+                    const int wnext = (wcur + 1) & (CB_NWB - 1);
                     if (tapi == 0) {                   // first step on a new window: nothing was prefetched
                         a_offsets(0, aoff);
                         load_frag(fa, aoff, wcur, 0);
                     }
                     const bool chain = tapi + 1 < ntaps;   // the next step reads the same window
                     // 4 k-steps; the fragments of the next one (or of the next step's first) ride under the MFMAs.
-                    // The step's bookkeeping (publishing the weight tile of step +2, fetching that of step +3,
-                    // the next tap's row offsets) sits behind the first MFMAs, not in front of them: both waves
+                    // The next tap's row offsets are computed behind MFMAs, not in front of the first: both waves
                     // of a SIMD leave the barrier together, and whatever precedes the first MFMA idles the pipe.
                     __builtin_amdgcn_sched_barrier(0);
+                    glds_w_next((wcur + 3) & (CB_NWB - 1));  // tile of step +3 into the buffer step -1 read
                     load_frag(fb, aoff, wcur, 1);
                     mma_frag(fa);
                     CB_INTERLEAVE(MT + NT, MT * NT)
                     __builtin_amdgcn_sched_barrier(0);
-                    store_w(wstore);                   // tile of step +2; its buffer was read during step -1
                     load_frag(fa, aoff, wcur, 2);
                     mma_frag(fb);
                     CB_INTERLEAVE(MT + NT, MT * NT)
                     __builtin_amdgcn_sched_barrier(0);
-                    load_w_next();                     // tile of step +3
                     if (chain) a_offsets(tapi + 1, aoff_n);
                     load_frag(fb, aoff, wcur, 3);
                     mma_frag(fa);
@@ -271,6 +273,7 @@ __global__ __launch_bounds__(WR * WC * 64) void conv_big_kernel(ConvBigArgs a) {
 #pragma unroll
                     for (int m = 0; m < MT; ++m) aoff[m] = aoff_n[m];
                     wcur = wnext;
+                    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(WPT) : "memory");   // tile of step +2 has landed
                 }
             }
         }
@@ -342,6 +345,7 @@ __global__ __launch_bounds__(WR * WC * 64) void conv_big_kernel(ConvBigArgs a) {
         b = nb; r0 = nr0; r1 = nr1; flo = nflo; wrows = nwrows;
     }
 
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // weight tiles fetched ahead for steps that never came
     if (a.stats) {
         __syncthreads();
         float* red = (float*)smem;                        // [NTH][16]
@@ -369,7 +373,7 @@ static int launch_conv_big(ConvBigArgs& a, hipStream_t stream) {
     constexpr int BM = WR * MT * 32;
     a.tiles_per_sample = ceil_div_i(a.Tv * a.V, BM);
     constexpr int BN = WC * NT * 32;
-    const size_t body = (size_t)CB_WIN_ROWS * CB_RS + 3 * (size_t)CB_BN_MAX * CB_RS;
+    const size_t body = (size_t)CB_WIN_ROWS * CB_RS + CB_NWB * (size_t)BN * CB_WRS;
     a.zero_row = (int)((body + CB_RS - 1) / CB_RS);
     const size_t lds = (size_t)(a.zero_row + 1) * CB_RS;
     const int nct = ceil_div_i(a.Cout, BN);

@@ -201,6 +201,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = trainer.step(x, labels)
+    host_issue = time.perf_counter() - t0                        # the host's share: launching, autograd bookkeeping
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -231,6 +232,7 @@ def main():
         line = {
             "metric": "train clips/sec, ST-GCN NTU-60 (T=300,V=25,M=2)", "value": round(clips / elapsed, 2), "unit": "clips/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "host_issue_ms_per_step": round(host_issue / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "NTU-RGB+D xsub training step (forward + cross-entropy + backward + SGD-nesterov), "
                                    "%d clips per GPU, T=%d, V=25, M=2, 60 classes, spatial K=3, dropout 0.5" % (args.batch, args.frames),

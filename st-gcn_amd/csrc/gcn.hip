@@ -82,8 +82,12 @@ __device__ __forceinline__ void chain_mma(f32x16& accy, const f32x16& accz, cons
 // step).  With NA <= 16 the next frame's rows are fetched into a second register set while this frame computes.
 // ADD: the launch has an addend; without one the prefetch registers of the addend are not allocated, which lets the
 // narrow forms (NA <= 4) run three workgroups per CU.
-template <typename T, int NA, bool ADD>
-__global__ __launch_bounds__(256, (NA >= 1 && NA <= 4 && (!ADD || ET<T>::IS_BF16)) ? 3 : 2) void gcn_fused_kernel(GcnFusedArgs a) {
+// NWV: waves (frames in flight) per workgroup.  Wide inputs whose weight image for two column tiles takes most of a
+// CU's LDS run ONE workgroup of 8 waves instead of two of 4 with one column tile each: the same two waves per SIMD,
+// but every frame fetched from L2 feeds twice the MFMAs.
+template <typename T, int NA, bool ADD, int NWV>
+__global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : (NA >= 1 && NA <= 4 && (!ADD || ET<T>::IS_BF16)) ? 3 : 2) void gcn_fused_kernel(GcnFusedArgs a) {
+    constexpr int NTHR = NWV * 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int ES = ET<T>::ES;
     constexpr int KSTEP = ET<T>::KSTEP;
@@ -109,7 +113,7 @@ __global__ __launch_bounds__(256, (NA >= 1 && NA <= 4 && (!ADD || ET<T>::IS_BF16
     {
         const int ppr = Cin * ES / 16;           // 16-byte pieces per row
         const int npieces = K * NC * ppr;
-        for (int p = tid; p < npieces; p += 256) {
+        for (int p = tid; p < npieces; p += NTHR) {
             const int seg = p % ppr, row = p / ppr;
             const int k = row / NC, nl = row - k * NC;
             const int n = nbase + nl;
@@ -117,11 +121,11 @@ __global__ __launch_bounds__(256, (NA >= 1 && NA <= 4 && (!ADD || ET<T>::IS_BF16
             if (n < Nout) v = *(const i32x4*)((const char*)a.w + (((size_t)k * Nout + n) * Cin) * ES + seg * 16);
             *(i32x4*)(wl + (size_t)row * RSW + seg * 16) = v;
         }
-        for (int e = tid; e < K * NC; e += 256) {
+        for (int e = tid; e < K * NC; e += NTHR) {
             const int k = e / NC, n = nbase + (e - k * NC);
             bl[e] = (a.bias && n < Nout) ? a.bias[(size_t)k * Nout + n] : 0.f;
         }
-        build_adj_chain_table<T>(tab, a.adj, K, V, tid, 256, a.adj_t != 0);
+        build_adj_chain_table<T>(tab, a.adj, K, V, tid, NTHR, a.adj_t != 0);
     }
     __syncthreads();
 
@@ -254,8 +258,8 @@ __global__ __launch_bounds__(256, (NA >= 1 && NA <= 4 && (!ADD || ET<T>::IS_BF16
     };
 
     {
-        const int fstep = gridDim.x * 4;
-        int f = blockIdx.x * 4 + wave;
+        const int fstep = gridDim.x * NWV;
+        int f = blockIdx.x * NWV + wave;
         i32x4 fa[NAP], fb[NAP];
         if constexpr (PF) {
             if (f < NF) {
@@ -285,7 +289,7 @@ __global__ __launch_bounds__(256, (NA >= 1 && NA <= 4 && (!ADD || ET<T>::IS_BF16
             }
         }
         __syncthreads();                               // every wave is done with its staging rows
-        float* red = (float*)(bl + (size_t)K * NC);    // [4 waves][2][NC]
+        float* red = (float*)(bl + (size_t)K * NC);    // [NWV waves][2][NC]
         if (lane < ppr) {
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
@@ -294,27 +298,36 @@ __global__ __launch_bounds__(256, (NA >= 1 && NA <= 4 && (!ADD || ET<T>::IS_BF16
             }
         }
         __syncthreads();
-        for (int t = tid; t < 2 * NC; t += 256) {
+        for (int t = tid; t < 2 * NC; t += NTHR) {
             const int which = t / NC, c = t - which * NC;
             if (c < ncols) {
-                const float v = red[(0 * 2 + which) * NC + c] + red[(1 * 2 + which) * NC + c] + red[(2 * 2 + which) * NC + c] + red[(3 * 2 + which) * NC + c];
+                float v = 0.f;
+#pragma unroll
+                for (int w = 0; w < NWV; ++w) v += red[(w * 2 + which) * NC + c];
                 atomicAdd(&a.stats[which * Nout + nbase + c], (double)v);
             }
         }
     }
 }
 
-template <typename T, int NA, bool ADD>
-static int gcn_fused_launch2(GcnFusedArgs& a, dim3 grid, size_t lds, hipStream_t stream) {
-    auto kern = gcn_fused_kernel<T, NA, ADD>;
+template <typename T, int NA, bool ADD, int NWV>
+static int gcn_fused_launch3(GcnFusedArgs& a, dim3 grid, size_t lds, hipStream_t stream) {
+    auto kern = gcn_fused_kernel<T, NA, ADD, NWV>;
     static bool set = false;
     if (!set) { if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return STGCN_ERR_LAUNCH; set = true; }
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, a);
+    hipLaunchKernelGGL(kern, grid, dim3(NWV * 64), lds, stream, a);
     return hipGetLastError() == hipSuccess ? STGCN_OK : STGCN_ERR_LAUNCH;
 }
+template <typename T, int NA, bool ADD>
+static int gcn_fused_launch2(GcnFusedArgs& a, dim3 grid, size_t lds, int nwv, hipStream_t stream) {
+    if constexpr (NA >= 8) {
+        if (nwv == 8) return gcn_fused_launch3<T, NA, ADD, 8>(a, grid, lds, stream);
+    }
+    return gcn_fused_launch3<T, NA, ADD, 4>(a, grid, lds, stream);
+}
 template <typename T, int NA>
-static int gcn_fused_launch(GcnFusedArgs& a, dim3 grid, size_t lds, hipStream_t stream) {
-    return a.add ? gcn_fused_launch2<T, NA, true>(a, grid, lds, stream) : gcn_fused_launch2<T, NA, false>(a, grid, lds, stream);
+static int gcn_fused_launch(GcnFusedArgs& a, dim3 grid, size_t lds, int nwv, hipStream_t stream) {
+    return a.add ? gcn_fused_launch2<T, NA, true>(a, grid, lds, nwv, stream) : gcn_fused_launch2<T, NA, false>(a, grid, lds, nwv, stream);
 }
 
 template <typename T>
@@ -324,30 +337,32 @@ static int gcn_fused_run(GcnFusedArgs& a, hipStream_t stream) {
     const size_t rsw = (size_t)a.Cin * ES + 16;
     // column tiles per workgroup (1, 2 or 4: the store phase wants a power-of-two piece count per row): the widest
     // that keeps the LDS image within half a CU, so two workgroups (two waves per SIMD) stay resident
-    auto lds_for = [&](int n) {
-        return (size_t)a.K * n * 32 * rsw + adj_chain_table_bytes<T>(a.K) + (size_t)a.K * n * 32 * 4 + (size_t)4 * 32 * (n * 32 * ES + 16);
+    auto lds_for = [&](int n, int nwv) {
+        return (size_t)a.K * n * 32 * rsw + adj_chain_table_bytes<T>(a.K) + (size_t)a.K * n * 32 * 4 + (size_t)nwv * 32 * (n * 32 * ES + 16);
     };
-    int ntw = 4;
-    while (ntw > 1 && (lds_for(ntw) > 80 * 1024 || (ntw / 2) * 32 >= a.Nout)) ntw /= 2;
-    const size_t lds = lds_for(ntw);
+    int ntw = 4, nwv = 4;
+    while (ntw > 1 && (lds_for(ntw, 4) > 80 * 1024 || (ntw / 2) * 32 >= a.Nout)) ntw /= 2;
+    const int na = a.Cin / KSTEP;
+    // one column tile per 4-wave workgroup is all that half a CU's LDS holds: take the whole CU with 8 waves and two
+    if (ntw == 1 && a.Nout > 32 && na >= 8 && (na & (na - 1)) == 0 && lds_for(2, 8) <= 160 * 1024) { ntw = 2; nwv = 8; }
+    const size_t lds = lds_for(ntw, nwv);
     if (lds > 160 * 1024) return STGCN_ERR_ARG;
     a.ntw = ntw;
     const int gy = ceil_div_i(a.Nout, ntw * 32);
     // persistent waves: as many workgroups as stay resident (2 per CU when the LDS image allows it)
-    const int na = a.Cin / KSTEP;
     const int per_cu = ((!a.add || ET<T>::IS_BF16) && na >= 1 && na <= 4 && 3 * lds <= 160 * 1024) ? 3 : lds <= 80 * 1024 ? 2 : 1;
     const int resident = per_cu * 256;
     int gx = max(1, resident / gy);
-    if (gx > ceil_div_i(a.NF, 4)) gx = ceil_div_i(a.NF, 4);
+    if (gx > ceil_div_i(a.NF, nwv)) gx = ceil_div_i(a.NF, nwv);
     const dim3 grid((unsigned)gx, (unsigned)gy);
     switch (a.Cin / KSTEP) {
-        case 1: return gcn_fused_launch<T, 1>(a, grid, lds, stream);
-        case 2: return gcn_fused_launch<T, 2>(a, grid, lds, stream);
-        case 4: return gcn_fused_launch<T, 4>(a, grid, lds, stream);
-        case 8: return gcn_fused_launch<T, 8>(a, grid, lds, stream);
-        case 16: return gcn_fused_launch<T, 16>(a, grid, lds, stream);
-        case 32: return gcn_fused_launch<T, 32>(a, grid, lds, stream);
-        default: return gcn_fused_launch<T, 0>(a, grid, lds, stream);
+        case 1: return gcn_fused_launch<T, 1>(a, grid, lds, nwv, stream);
+        case 2: return gcn_fused_launch<T, 2>(a, grid, lds, nwv, stream);
+        case 4: return gcn_fused_launch<T, 4>(a, grid, lds, nwv, stream);
+        case 8: return gcn_fused_launch<T, 8>(a, grid, lds, nwv, stream);
+        case 16: return gcn_fused_launch<T, 16>(a, grid, lds, nwv, stream);
+        case 32: return gcn_fused_launch<T, 32>(a, grid, lds, nwv, stream);
+        default: return gcn_fused_launch<T, 0>(a, grid, lds, nwv, stream);
     }
 }
 

@@ -21,3 +21,8 @@ small = [(k, v) for k, v in agg.items() if v[1] / v[0] < 20000]
 print("kernels under 20 us: %d launches, %.3f ms" % (sum(v[0] for _, v in small), sum(v[1] for _, v in small) / 1e6))
 for k, v in sorted(small, key=lambda kv: -kv[1][1])[:16]:
     print("  %3d x %6.1f us  %s" % (v[0], v[1] / v[0] / 1e3, k))
+print("largest gaps:")
+for g, i in sorted(((g, i) for i, g in enumerate(gaps)), reverse=True)[:10]:
+    print("  %6.1f us  after %-40s before %s" % (g / 1e3, step[i]["Kernel_Name"][:40], step[i + 1]["Kernel_Name"][:40]))
+hist = collections.Counter(min(int(g / 1000), 10) for g in gaps if g > 0)
+print("gap histogram (us: count):", sorted(hist.items()))

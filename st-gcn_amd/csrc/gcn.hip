@@ -386,9 +386,11 @@ struct GcnAgradArgs {
 };
 
 // NA as in gcn_fused_kernel.  Each wave keeps the K 32x32 partial dA tiles in accumulators over all its frames;
-// the four waves' tiles are summed through LDS at the end and the workgroup writes one partial to the slab.
-template <typename T, int NA>
-__global__ __launch_bounds__(256, 2) void gcn_agrad_kernel(GcnAgradArgs a) {
+// the waves' tiles are summed through LDS at the end and the workgroup writes one partial to the slab.  NWV (waves
+// per workgroup) as in gcn_fused_kernel.
+template <typename T, int NA, int NWV>
+__global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : 2) void gcn_agrad_kernel(GcnAgradArgs a) {
+    constexpr int NTHR = NWV * 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int ES = ET<T>::ES;
     constexpr int KSTEP = ET<T>::KSTEP;
@@ -409,7 +411,7 @@ __global__ __launch_bounds__(256, 2) void gcn_agrad_kernel(GcnAgradArgs a) {
     {
         const int ppr = Cin * ES / 16;
         const int npieces = K * NC * ppr;
-        for (int p = tid; p < npieces; p += 256) {
+        for (int p = tid; p < npieces; p += NTHR) {
             const int seg = p % ppr, row = p / ppr;
             const int k = row / NC, nl = row - k * NC;
             const int co = cbase + nl;
@@ -417,7 +419,7 @@ __global__ __launch_bounds__(256, 2) void gcn_agrad_kernel(GcnAgradArgs a) {
             if (co < Cout) v = *(const i32x4*)((const char*)a.w + (((size_t)k * Cout + co) * Cin) * ES + seg * 16);
             *(i32x4*)(wl + (size_t)row * RSW + seg * 16) = v;
         }
-        for (int e = tid; e < K * NC; e += 256) {
+        for (int e = tid; e < K * NC; e += NTHR) {
             const int k = e / NC, co = cbase + (e - k * NC);
             bl[e] = (a.bias && co < Cout) ? a.bias[(size_t)k * Cout + co] : 0.f;
         }
@@ -521,8 +523,8 @@ __global__ __launch_bounds__(256, 2) void gcn_agrad_kernel(GcnAgradArgs a) {
     };
 
     {
-        const int fstep = gridDim.x * 4;
-        int f = blockIdx.x * 4 + wave;
+        const int fstep = gridDim.x * NWV;
+        int f = blockIdx.x * NWV + wave;
         i32x4 fa[NAP], fb[NAP];
         if constexpr (PF) {
             if (f < NF) {
@@ -540,9 +542,9 @@ __global__ __launch_bounds__(256, 2) void gcn_agrad_kernel(GcnAgradArgs a) {
             f += fstep;
         }
     }
-    // accd[k]: row = v (registers), col = w (lane).  Sum the four waves through LDS, one k at a time.
+    // accd[k]: row = v (registers), col = w (lane).  Sum the waves through LDS, one k at a time.
     const size_t part = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
-    float* red = (float*)smem;                   // [4][16][64] floats (weights are dead now)
+    float* red = (float*)smem;                   // [NWV][16][64] floats (weights are dead now)
 #pragma unroll
     for (int k = 0; k < GCN_KMAX; ++k) {
         if (k < K) {
@@ -550,11 +552,15 @@ __global__ __launch_bounds__(256, 2) void gcn_agrad_kernel(GcnAgradArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = accd[k][r];
             __syncthreads();
-            for (int e = tid; e < 16 * 64; e += 256) {
+            for (int e = tid; e < 16 * 64; e += NTHR) {
                 const int r = e >> 6, ln = e & 63;
                 const int v = acc_row(r, ln >> 5), w = ln & 31;
-                if (v < V && w < V)
-                    a.slab[((part * K + k) * V + v) * V + w] = red[e] + red[16 * 64 + e] + red[2 * 16 * 64 + e] + red[3 * 16 * 64 + e];
+                if (v < V && w < V) {
+                    float t = 0.f;
+#pragma unroll
+                    for (int wv = 0; wv < NWV; ++wv) t += red[wv * 16 * 64 + e];
+                    a.slab[((part * K + k) * V + v) * V + w] = t;
+                }
             }
         }
     }
@@ -592,13 +598,20 @@ __global__ __launch_bounds__(256) void sum_parts_wave_kernel(const float* slab, 
     if (lane == 0) out[i] = s;
 }
 
-template <typename T, int NA>
-static int gcn_agrad_launch(GcnAgradArgs& a, dim3 grid, size_t lds, hipStream_t stream) {
-    auto kern = gcn_agrad_kernel<T, NA>;
+template <typename T, int NA, int NWV>
+static int gcn_agrad_launch2(GcnAgradArgs& a, dim3 grid, size_t lds, hipStream_t stream) {
+    auto kern = gcn_agrad_kernel<T, NA, NWV>;
     static bool set = false;
     if (!set) { if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return STGCN_ERR_LAUNCH; set = true; }
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, a);
+    hipLaunchKernelGGL(kern, grid, dim3(NWV * 64), lds, stream, a);
     return hipGetLastError() == hipSuccess ? STGCN_OK : STGCN_ERR_LAUNCH;
+}
+template <typename T, int NA>
+static int gcn_agrad_launch(GcnAgradArgs& a, dim3 grid, size_t lds, int nwv, hipStream_t stream) {
+    if constexpr (NA >= 8) {
+        if (nwv == 8) return gcn_agrad_launch2<T, NA, 8>(a, grid, lds, stream);
+    }
+    return gcn_agrad_launch2<T, NA, 4>(a, grid, lds, stream);
 }
 
 template <typename T>
@@ -608,26 +621,35 @@ static int gcn_agrad_run(GcnAgradArgs& a, float* dA, size_t ws_bytes, hipStream_
     const size_t rsw = (size_t)a.Cin * ES + 16;
     int ntw = 4;
     while (ntw > 1 && ((size_t)a.K * ntw * 32 * rsw > 72 * 1024 || (ntw - 1) * 32 >= a.Cout)) --ntw;
+    const int na = a.Cin / KSTEP;
+    int nwv = 4;
+    // Wide inputs: half a CU's LDS holds few column tiles, and every tile re-reads the frame from L2.  One 8-wave
+    // workgroup with the whole CU's LDS (the same two waves per SIMD) takes twice the tiles per frame fetched.
+    if (na >= 8 && (na & (na - 1)) == 0 && na <= 16) {
+        int ntw8 = 4;                                // 4 or 2: equal column tiles for the usual power-of-two widths
+        while (ntw8 > 1 && ((size_t)a.K * ntw8 * 32 * (rsw + 4) > 150 * 1024 || ntw8 * 32 > a.Cout)) ntw8 /= 2;
+        if (ntw8 > ntw) { ntw = ntw8; nwv = 8; }
+    }
     size_t lds = (size_t)a.K * ntw * 32 * rsw + (size_t)a.K * ntw * 32 * 4;
-    if (lds < 16 * 1024) lds = 16 * 1024;        // the final cross-wave reduction uses 16 KiB
+    if (lds < (size_t)nwv * 4096) lds = (size_t)nwv * 4096;   // the final cross-wave reduction uses 4 KiB per wave
     if (lds > 160 * 1024) return STGCN_ERR_ARG;
     a.ntw = ntw;
     const int gy = ceil_div_i(a.Cout, ntw * 32);
     const int resident = (lds <= 80 * 1024 ? 2 : 1) * 256;
     int gx = max(1, resident / gy);
-    if (gx > ceil_div_i(a.NF, 4)) gx = ceil_div_i(a.NF, 4);
+    if (gx > ceil_div_i(a.NF, nwv)) gx = ceil_div_i(a.NF, nwv);
     const size_t n = (size_t)a.K * a.V * a.V;
     if ((size_t)gx * gy * n * sizeof(float) > ws_bytes) return STGCN_ERR_WORKSPACE;
     const dim3 grid((unsigned)gx, (unsigned)gy);
     int rc;
     switch (a.Cin / KSTEP) {
-        case 1: rc = gcn_agrad_launch<T, 1>(a, grid, lds, stream); break;
-        case 2: rc = gcn_agrad_launch<T, 2>(a, grid, lds, stream); break;
-        case 4: rc = gcn_agrad_launch<T, 4>(a, grid, lds, stream); break;
-        case 8: rc = gcn_agrad_launch<T, 8>(a, grid, lds, stream); break;
-        case 16: rc = gcn_agrad_launch<T, 16>(a, grid, lds, stream); break;
-        case 32: rc = gcn_agrad_launch<T, 32>(a, grid, lds, stream); break;
-        default: rc = gcn_agrad_launch<T, 0>(a, grid, lds, stream); break;
+        case 1: rc = gcn_agrad_launch<T, 1>(a, grid, lds, nwv, stream); break;
+        case 2: rc = gcn_agrad_launch<T, 2>(a, grid, lds, nwv, stream); break;
+        case 4: rc = gcn_agrad_launch<T, 4>(a, grid, lds, nwv, stream); break;
+        case 8: rc = gcn_agrad_launch<T, 8>(a, grid, lds, nwv, stream); break;
+        case 16: rc = gcn_agrad_launch<T, 16>(a, grid, lds, nwv, stream); break;
+        case 32: rc = gcn_agrad_launch<T, 32>(a, grid, lds, nwv, stream); break;
+        default: rc = gcn_agrad_launch<T, 0>(a, grid, lds, nwv, stream); break;
     }
     if (rc != STGCN_OK) return rc;
     hipLaunchKernelGGL(sum_parts_wave_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, a.slab, dA, gx * gy, n);

@@ -7,6 +7,14 @@ cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 $R/bench.py --no-cpu-baseline > $O/kt.log 2>&1 || exit 1
 KS=$(ls $O/kt/*/*kernel_stats.csv | head -1); cp $KS $O/kernel_stats.csv
 KT=$(ls $O/kt/*/*kernel_trace.csv | head -1); python $R/tools/step_trace.py $KT > $O/step_launch_summary.txt 2>&1
+# every dispatch of the kernel priced in the bench line's roofline (several shapes share the name)
+python - $KT > $O/dominant_kernel_dispatches.csv <<'PY'
+import csv, sys
+rows = [r for r in csv.DictReader(open(sys.argv[1])) if "conv_big_kernel<bf16, 4, 2, 2, 2, 1>" in r["Kernel_Name"]]
+print("start_ns,duration_us,grid,workgroup")
+for r in sorted(rows, key=lambda r: int(r["Start_Timestamp"])):
+    print("%s,%.1f,%s,%s" % (r["Start_Timestamp"], (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3, r.get("Grid_Size", r.get("Grid_Size_X", "")), r.get("Workgroup_Size", r.get("Workgroup_Size_X", ""))))
+PY
 rm -rf $O/kt
 timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/p1 -- python3 $R/tools/kbench.py conv_t_epi:256:256 --iters 5 > $O/p1.log 2>&1 || exit 1
 timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/p2 -- python3 $R/tools/kbench.py conv_t_epi:256:256 --iters 5 > $O/p2.log 2>&1 || exit 1
@@ -17,3 +25,8 @@ timeout -s KILL 240 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_LDS_BAN
 python $R/tools/pmc_summary.py $(ls $O/p3/*/*counter_collection.csv | head -1) > $O/pmc_per_kernel_summary.txt
 rm -rf $O/p3
 echo PROF_DONE
+# the dominant kernel alone at the roofline shape, so that the --stats average is per shape
+cd /tmp
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kd -- python3 $R/tools/kbench.py conv_t_epi:256:256 --iters 20 > $O/kd.log 2>&1 || exit 1
+cp $(ls $O/kd/*/*kernel_stats.csv | head -1) $O/dominant_kernel_stats.csv; rm -rf $O/kd
+echo PROF_DONE2

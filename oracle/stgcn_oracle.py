@@ -21,7 +21,9 @@ function here against them.
 
 All tensors are torch CPU tensors in the reference's logical layout
 (x: [B, C, T, V]); dtype follows the inputs (float64 for pinning, float32 for
-the timed CPU baseline).
+the timed CPU baseline).  The graph-convolution and temporal-convolution
+functions allocate on their inputs' device, so that the full-size GPU tests can
+evaluate these same float64 formulas on whole training-step tensors in seconds.
 """
 from __future__ import annotations
 
@@ -203,7 +205,7 @@ def gcn_backward(x, A, W, b, dy):
     dx = torch.zeros_like(x)
     dW = torch.zeros_like(Wk)
     dA = torch.zeros_like(A)
-    db = None if b is None else torch.zeros(K, Cout, dtype=x.dtype)
+    db = None if b is None else torch.zeros(K, Cout, dtype=x.dtype, device=x.device)
     S = dy.sum(dim=(0, 2))                                  # [Cout, W]
     for k in range(K):
         dz = torch.matmul(dy, A[k].t())                     # [B,Cout,T,V]  grad of projected z_k
@@ -235,7 +237,7 @@ def tconv_forward(h, W, b, stride=1, pad=None, dil=1):
     pad = (kt - 1) // 2 if pad is None else pad
     B, _, T, V = h.shape
     To = tconv_out_len(T, kt, stride, pad, dil)
-    o = torch.zeros(B, Cout, To, V, dtype=h.dtype)
+    o = torch.zeros(B, Cout, To, V, dtype=h.dtype, device=h.device)
     tp = torch.arange(To)
     for dt in range(kt):
         ti = stride * tp + dt * dil - pad

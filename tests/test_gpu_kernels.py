@@ -214,7 +214,8 @@ def test_gcn_kernels(rt, case, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
-@pytest.mark.parametrize("Cc,rows_shape", [(64, (2, 20, 25)), (128, (1, 19, 18)), (256, (2, 5, 25)), (96, (1, 7, 25)), (64, (3, 300, 25))])
+@pytest.mark.parametrize("Cc,rows_shape", [(64, (2, 20, 25)), (128, (1, 19, 18)), (256, (2, 5, 25)), (96, (1, 7, 25)), (64, (3, 300, 25)),
+                                            (64, (128, 300, 25))])       # the benchmarked step's largest activation: 960 000 rows
 def test_block_out_and_bn_kernels(rt, Cc, rows_shape, dtype):
     B, T, V = rows_shape
     o = q(t64((B, Cc, T, V), 51), dtype)

@@ -1063,7 +1063,9 @@ static int gcn_wgrad_wide_try(const void* x, const void* dy, const float* adj, f
     const size_t lds = (size_t)K * 2 * 64 * 16 + (size_t)fb * per_frame + 32;
     if (lds > 160 * 1024) return -1;
     const int gy = ceil_div_i(Cout, 64);
-    int gx = max(1, 256 / gy);
+    // as many workgroups as stay resident: narrow inputs run few waves per workgroup and leave LDS for three
+    const int per_cu = nt <= 384 && 3 * lds <= 160 * 1024 ? 3 : nt <= 512 && 2 * lds <= 160 * 1024 ? 2 : 1;
+    int gx = max(1, per_cu * 256 / gy);
     const size_t nW = (size_t)K * Cout * Cin, nB = (size_t)K * Cout;
     while (gx > 1 && (size_t)gx * (nW + nB) * sizeof(float) > ws_bytes) gx /= 2;
     if ((size_t)gx * (nW + nB) * sizeof(float) > ws_bytes) return STGCN_ERR_WORKSPACE;

@@ -161,7 +161,7 @@ __global__ __launch_bounds__(WR * WC * 64) void conv_big_kernel(ConvBigArgs a) {
                                              16, 0, 0);
     };
     // Tile g of the (chunk-major, then tap) sequence -- the same for every row tile of this workgroup, so it just
-    // wraps around -- lives in buffer g % 4.  Its loads are issued at the start of step g-3 (the buffer was last read
+    // wraps around -- lives in buffer g % 4.  Its loads are issued early in step g-3 (the buffer was last read
     // during step g-4), waited for by each wave at the end of step g-2 (a counted wait that leaves the loads of step
     // g-2 itself in flight), published by the barrier that opens step g-1, and read during step g; its first
     // fragments are already read at the end of step g-1.
@@ -252,12 +252,12 @@ __global__ __launch_bounds__(WR * WC * 64) void conv_big_kernel(ConvBigArgs a) {
                     // The next tap's row offsets are computed behind MFMAs, not in front of the first: both waves
                     // of a SIMD leave the barrier together, and whatever precedes the first MFMA idles the pipe.
                     __builtin_amdgcn_sched_barrier(0);
-                    glds_w_next((wcur + 3) & (CB_NWB - 1));  // tile of step +3 into the buffer step -1 read
                     load_frag(fb, aoff, wcur, 1);
                     mma_frag(fa);
                     CB_INTERLEAVE(MT + NT, MT * NT)
                     __builtin_amdgcn_sched_barrier(0);
-                    load_frag(fa, aoff, wcur, 2);
+                    glds_w_next((wcur + 3) & (CB_NWB - 1));  // tile of step +3 into the buffer step -1 read; behind
+                    load_frag(fa, aoff, wcur, 2);            // the first MFMA group: nothing should delay that one
                     mma_frag(fb);
                     CB_INTERLEAVE(MT + NT, MT * NT)
                     __builtin_amdgcn_sched_barrier(0);

@@ -25,8 +25,3 @@ timeout -s KILL 240 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_LDS_BAN
 python $R/tools/pmc_summary.py $(ls $O/p3/*/*counter_collection.csv | head -1) > $O/pmc_per_kernel_summary.txt
 rm -rf $O/p3
 echo PROF_DONE
-# the dominant kernel alone at the roofline shape, so that the --stats average is per shape
-cd /tmp
-timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kd -- python3 $R/tools/kbench.py conv_t_epi:256:256 --iters 20 > $O/kd.log 2>&1 || exit 1
-cp $(ls $O/kd/*/*kernel_stats.csv | head -1) $O/dominant_kernel_stats.csv; rm -rf $O/kd
-echo PROF_DONE2

@@ -164,6 +164,8 @@ GCN_DIRECT = [
     ("ntu-rgb+d", "spatial", False, 4, 256, 256, 6),
     ("ntu-rgb+d", "spatial", True, 4, 48, 80, 600),      # odd widths (any-width paths), several batches per workgroup
     ("openpose", "distance", True, 3, 64, 64, 301),
+    ("ntu-rgb+d", "spatial", True, 2, 256, 80, 7),         # 8-wave workgroups with a ragged last column tile
+    ("openpose", "spatial", False, 3, 128, 208, 9),
 ]
 
 

@@ -170,8 +170,16 @@ __global__ __launch_bounds__(WR * WC * 64) void conv_big_kernel(ConvBigArgs a) {
         glds_w(wi_chunk, wi_tap, buf);
         if (++wi_tap == ntaps) { wi_tap = 0; if (++wi_chunk == nchunks) wi_chunk = 0; }
     };
-    int ti = blockIdx.x;
-    if (ti >= ntile_total) return;
+    // Tile walk.  Workgroups go to the 8 XCDs round-robin by linear id, and each XCD has its own L2: XCD q takes the
+    // q-th eighth of the (sample-major) tile sequence and its workgroups walk it side by side, so the tiles in flight
+    // on one L2 are neighbours -- their windows overlap by the taps' halo (8 of ~20 frames) and the other column
+    // tile of the same rows has the same blockIdx.x.  Grids that are not a multiple of 8 walk the plain stride.
+    const bool xcd_walk = (gridDim.x & 7) == 0 && ntile_total >= (int)gridDim.x;
+    const int wq = blockIdx.x & 7, wr_ = blockIdx.x >> 3, wpx = gridDim.x >> 3;
+    const int t_hi = xcd_walk ? (int)(((long long)ntile_total * (wq + 1)) >> 3) : ntile_total;
+    const int t_step = xcd_walk ? wpx : (int)gridDim.x;
+    int ti = xcd_walk ? (int)(((long long)ntile_total * wq) >> 3) + wr_ : (int)blockIdx.x;
+    if (ti >= t_hi) return;
     int b, r0, r1, flo, wrows;
     tile_geo(ti, b, r0, r1, flo, wrows);
     if (ntaps > 0) {
@@ -183,7 +191,7 @@ __global__ __launch_bounds__(WR * WC * 64) void conv_big_kernel(ConvBigArgs a) {
     }
     int wcur = 0;                                          // buffer of the current step's weight tile
 
-    for (; ti < ntile_total; ti += gridDim.x) {
+    for (; ti < t_hi; ti += t_step) {
         // this lane's output rows (one per row subtile)
         int t_out[MT], vj[MT];
         bool rvalid[MT];
@@ -204,9 +212,9 @@ __global__ __launch_bounds__(WR * WC * 64) void conv_big_kernel(ConvBigArgs a) {
                 for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
 
         // geometry of the next tile (its first window is prefetched during this tile's last chunk)
-        const int tn = ti + gridDim.x;
+        const int tn = ti + t_step;
         int nb = 0, nr0 = 0, nr1 = 0, nflo = 0, nwrows = 0;
-        if (tn < ntile_total) tile_geo(tn, nb, nr0, nr1, nflo, nwrows);
+        if (tn < t_hi) tile_geo(tn, nb, nr0, nr1, nflo, nwrows);
 
         if (ntaps > 0) {
             struct Frag { i32x4 af[MT]; i32x4 bf[NT]; };
@@ -239,7 +247,7 @@ __global__ __launch_bounds__(WR * WC * 64) void conv_big_kernel(ConvBigArgs a) {
                 lds_barrier();                             // previous window / epilogue staging fully consumed
                 commit_win(wrows, chunk);
                 if (chunk + 1 < nchunks) fetch_win(b, flo, wrows, chunk + 1);
-                else if (tn < ntile_total) fetch_win(nb, nflo, nwrows, 0);
+                else if (tn < t_hi) fetch_win(nb, nflo, nwrows, 0);
                 for (int tapi = 0; tapi < ntaps; ++tapi) {
                     lds_barrier();                         // weight tile of this step (and a new window) visible
                     const int wnext = (wcur + 1) & (CB_NWB - 1);

@@ -81,7 +81,15 @@ def ptr(t):
     return t.data_ptr()
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_get_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def stream_ptr():
+    """The current stream's handle.  torch.cuda.current_stream() builds a Stream object per call (about 9 us: a
+    fifth of the host's time per training step, which is what bounds small batches); the raw accessor does not."""
+    if _raw_stream is not None and _get_device is not None:
+        return _raw_stream(_get_device())
     return torch.cuda.current_stream().cuda_stream
 
 

@@ -114,7 +114,9 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--batch", type=int, default=64, help="clips per GPU")
+    ap.add_argument("--batch", type=int, default=64, help="clips per GPU (weak scaling) or in total (--strong)")
+    ap.add_argument("--strong", action="store_true",
+                    help="strong scaling: --batch is the global batch (the reference's 64), split evenly over the GPUs")
     ap.add_argument("--frames", type=int, default=300)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-clips", type=int, default=2)
@@ -167,6 +169,10 @@ def main():
     trainer.broadcast_from_rank0()
 
     gen = torch.Generator().manual_seed(rank)                   # synthetic data: x ~ N(0,1), labels uniform
+    if args.strong:
+        if args.batch % world != 0:
+            raise SystemExit("--strong: the global batch %d does not split over %d GPUs" % (args.batch, world))
+        args.batch //= world                                    # clips per GPU from here on
     x = torch.randn(args.batch, 3, args.frames, 25, 2, generator=gen).to(dev)
     labels = torch.randint(0, 60, (args.batch,), generator=gen).to(dev)
 
@@ -233,7 +239,7 @@ def main():
             "metric": "train clips/sec, ST-GCN NTU-60 (T=300,V=25,M=2)", "value": round(clips / elapsed, 2), "unit": "clips/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "host_issue_ms_per_step": round(host_issue / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "NTU-RGB+D xsub training step (forward + cross-entropy + backward + SGD-nesterov), "
                                    "%d clips per GPU, T=%d, V=25, M=2, 60 classes, spatial K=3, dropout 0.5" % (args.batch, args.frames),
                        "global_batch": args.batch * world, "parallelism": "dp%d" % world, "final_loss": round(float(loss.item()), 4)},

@@ -1,7 +1,8 @@
 """TEST INFRASTRUCTURE -- CPU restatement of the reference's clip augmentation (hensyou/st-gcn feeder/tools.py),
 with the random draws passed in, frame by frame as the reference loops.  Imported only by tests/ (and never by the
-product path).  Pinned by hand-checkable cases in tests/test_feeder.py; the reference's feeder package cannot be
-imported here (torchvision missing), so those are the pins.
+product path).  Pinned by tests/golden/feeder.npz: outputs of the reference's own feeder/tools.py on closed-form
+clips with seeded generators (tests/golden/make_golden.py gen_feeder; feeder.tools needs only numpy and random --
+feeder.feeder itself wants torchvision and is not importable), plus hand-checkable cases in tests/test_feeder.py.
 """
 import numpy as np
 

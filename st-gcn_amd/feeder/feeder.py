@@ -38,7 +38,13 @@ def load_label_file(path):
 class Feeder(torch.utils.data.Dataset):
     """Arguments as the reference's Feeder: data_path, label_path, random_choose (random window of window_size
     frames), random_move (random affine motion of the x-y plane), window_size (> 0 without random_choose: pad
-    shorter clips), debug (first 100 clips), mmap."""
+    shorter clips), debug (first 100 clips), mmap.
+
+    An item runs the clip through a list of stages fixed at construction (window stage, then move stage);
+    `item_with_draws` returns the untouched clip together with the random draws of those stages instead, for batches
+    whose arithmetic runs on the GPU (stgcn_rt.ops.augment_batch)."""
+
+    DEBUG_CLIPS = 100
 
     def __init__(self, data_path, label_path, random_choose=False, random_move=False, window_size=-1, debug=False,
                  mmap=True):
@@ -50,25 +56,41 @@ class Feeder(torch.utils.data.Dataset):
         self.window_size = window_size
         self.load_data(mmap)
 
+    def _stages(self):
+        stages = []
+        if self.random_choose:
+            stages.append(lambda clip: tools.random_choose(clip, self.window_size))
+        elif self.window_size > 0:
+            stages.append(lambda clip: tools.auto_pading(clip, self.window_size))
+        if self.random_move:
+            stages.append(tools.random_move)
+        return stages
+
     def load_data(self, mmap):
-        self.sample_name, self.label = load_label_file(self.label_path)
-        self.data = np.load(self.data_path, mmap_mode="r") if mmap else np.load(self.data_path)
-        if self.debug:
-            self.label = self.label[0:100]
-            self.data = self.data[0:100]
-            self.sample_name = self.sample_name[0:100]
+        names, labels = load_label_file(self.label_path)
+        clips = np.load(self.data_path, mmap_mode="r" if mmap else None)
+        keep = self.DEBUG_CLIPS if self.debug else len(labels)
+        self.sample_name, self.label, self.data = names[:keep], labels[:keep], clips[:keep]
         self.N, self.C, self.T, self.V, self.M = self.data.shape
 
     def __len__(self):
         return len(self.label)
 
     def __getitem__(self, index):
-        data = np.array(self.data[index])
-        label = self.label[index]
+        clip = np.array(self.data[index])
+        for stage in self._stages():
+            clip = stage(clip)
+        return clip, self.label[index]
+
+    def item_with_draws(self, index, rng=None, nprng=None):
+        """-> (raw clip (C,T,V,M), label, shift or None, (a, s, tx, ty) or None): what __getitem__ would draw, in the
+        same order, without applying it."""
+        size = self.window_size
+        shift = move = None
         if self.random_choose:
-            data = tools.random_choose(data, self.window_size)
-        elif self.window_size > 0:
-            data = tools.auto_pading(data, self.window_size)
+            shift = tools.choose_shift(self.T, size, rng=rng)
+        elif 0 < self.T < size:
+            shift = 0
         if self.random_move:
-            data = tools.random_move(data)
-        return data, label
+            move = tools.move_params(size if shift is not None else self.T, rng=rng, nprng=nprng)
+        return np.array(self.data[index]), self.label[index], shift, move

@@ -17,13 +17,6 @@ def downsample(data, step, random_sample=True, rng=None):
     return data[:, begin::step, :, :]
 
 
-def temporal_slice(data, step):
-    """(C, T, V, M) -> (C, T/step, V, step*M): `step` consecutive frames become extra bodies (tools.py:11-15;
-    the reference divides with `/`, which only ran under Python 2 -- integer division is what it meant)."""
-    C, T, V, M = data.shape
-    return data.reshape(C, T // step, step, V, M).transpose((0, 1, 3, 2, 4)).reshape(C, T // step, V, step * M)
-
-
 def mean_subtractor(data, mean):
     """Subtract `mean` from every frame up to the last non-empty one, in place (tools.py:18-28).  mean == 0
     returns None, as the reference does."""

@@ -47,7 +47,62 @@ MODEL_CASES = [
     ("ntu_full_train", "ntu-rgb+d", 60, 2, 300, 2, True),
     ("kin_full_eval", "openpose", 400, 2, 300, 2, False),
     ("kin_t150_train", "openpose", 400, 2, 150, 2, True),          # 150 -> 75 -> 38
+    # partition strategies other than spatial (K = 1 / 2): graph.py:85-94 of the reference
+    ("ntu_uniform_eval", "ntu-rgb+d", 60, 2, 24, 2, False),
+    ("ntu_distance_eval", "ntu-rgb+d", 60, 2, 24, 2, False),
+    ("kin_uniform_eval", "openpose", 400, 2, 38, 2, False),
+    ("kin_distance_eval", "openpose", 400, 2, 38, 2, False),
+    ("ntu_uniform_train", "ntu-rgb+d", 60, 2, 24, 2, True),
+    ("kin_distance_train", "openpose", 400, 2, 38, 2, True),
 ]
+
+
+def strategy_of(name):
+    """Partition strategy of a model case (its name says so; spatial otherwise)."""
+    for s in ("uniform", "distance"):
+        if "_%s_" % s in name:
+            return s
+    return "spatial"
+
+
+# (name, function of feeder/tools.py, clip shape (C,T,V,M), (first, last+1) non-empty frame or None, kwargs,
+#  seed of `random`, seed of `numpy.random`)
+FEEDER_CASES = [
+    ("choose_crop", "random_choose", (3, 40, 25, 2), None, dict(size=24), 11, 0),
+    ("choose_crop_kin", "random_choose", (3, 300, 18, 2), None, dict(size=150), 12, 0),
+    ("choose_pad", "random_choose", (3, 20, 18, 2), None, dict(size=32), 13, 0),
+    ("choose_same", "random_choose", (3, 20, 18, 2), None, dict(size=20), 14, 0),
+    ("choose_short_nopad", "random_choose", (3, 20, 18, 2), None, dict(size=32, auto_pad=False), 15, 0),
+    ("pad_front", "auto_pading", (3, 20, 25, 2), None, dict(size=30), 16, 0),
+    ("pad_random", "auto_pading", (3, 20, 25, 2), None, dict(size=30, random_pad=True), 17, 0),
+    ("pad_none", "auto_pading", (3, 20, 25, 2), None, dict(size=10), 18, 0),
+    ("move_default", "random_move", (3, 24, 25, 2), None, dict(), 21, 31),
+    ("move_kin150", "random_move", (3, 150, 18, 2), None, dict(), 22, 32),
+    ("move_two_segments", "random_move", (3, 30, 18, 2), None, dict(move_time_candidate=[2]), 23, 33),
+    ("move_three_segments", "random_move", (3, 31, 25, 1), None,
+     dict(move_time_candidate=[3], angle_candidate=[-30., 0., 30.], scale_candidate=[0.5, 1.5], transform_candidate=[-1., 1.]), 24, 34),
+    ("shift_mid", "random_shift", (3, 40, 25, 2), (7, 22), dict(), 41, 0),
+    ("shift_full", "random_shift", (3, 16, 18, 2), None, dict(), 42, 0),
+    ("shift_tail", "random_shift", (3, 40, 25, 2), (25, 40), dict(), 43, 0),
+    ("downsample_random", "downsample", (3, 41, 25, 2), None, dict(step=3), 0, 51),
+    ("downsample_first", "downsample", (3, 41, 25, 2), None, dict(step=4, random_sample=False), 0, 52),
+    ("mean_sub", "mean_subtractor", (3, 40, 25, 2), (5, 30), dict(mean=0.25), 0, 0),
+    ("mean_sub_zero", "mean_subtractor", (3, 40, 25, 2), (5, 30), dict(mean=0), 0, 0),
+    # Feeder.__getitem__ (feeder.py:79-84): random_choose, then random_move on its result
+    ("pipeline_kin", "pipeline", (3, 300, 18, 2), None, dict(size=150), 61, 71),
+    ("pipeline_pad", "pipeline", (3, 20, 25, 2), None, dict(size=32), 62, 72),
+    ("pipeline_ntu", "pipeline", (3, 64, 25, 2), (0, 50), dict(size=48), 63, 73),
+]
+
+
+def feeder_clip(name, shape, gap):
+    """Closed-form clip (C,T,V,M) float64 in [-1, 1); frames outside gap = (first, last+1) are empty (all zero)."""
+    tag = 7000 + sum(ord(c) * (i + 1) for i, c in enumerate(name)) % 1000
+    d = np.array(O.det_uniform(shape, tag), dtype=np.float64)
+    if gap is not None:
+        d[:, :gap[0]] = 0
+        d[:, gap[1]:] = 0
+    return d
 
 
 def t64(a):

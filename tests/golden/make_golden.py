@@ -2,7 +2,8 @@
 
 Run in the build container only (needs /root/reference):
     python tests/golden/make_golden.py
-It imports net.st_gcn / net.utils.tgcn / net.utils.graph from /root/reference, feeds
+It imports net.st_gcn / net.utils.tgcn / net.utils.graph (and feeder.tools, which needs only numpy and
+random) from /root/reference, feeds
 them closed-form deterministic inputs and weights (oracle.stgcn_oracle.det_uniform,
 no library RNG) in float64, and stores the outputs.  Inputs are NOT stored: tests
 regenerate them from the same closed form.  Nothing from the reference's source is
@@ -27,8 +28,8 @@ from net.utils.tgcn import ConvTemporalGraphical as RefGCN  # noqa: E402
 
 torch.set_default_dtype(torch.float64)
 
-from tests.golden.cases import (GRAPH_CASES, GCN_CASES, BLOCK_CASES, MODEL_CASES, t64, compact,  # noqa: E402
-                                gcn_inputs, block_inputs, model_inputs)
+from tests.golden.cases import (GRAPH_CASES, GCN_CASES, BLOCK_CASES, MODEL_CASES, FEEDER_CASES, t64, compact,  # noqa: E402
+                                gcn_inputs, block_inputs, model_inputs, feeder_clip, strategy_of)
 
 
 def gen_graphs():
@@ -111,11 +112,12 @@ def gen_block():
 def gen_model():
     out = {}
     for ci, (name, lay, ncls, N, T, M, training) in enumerate(MODEL_CASES):
-        g = O.build_graph(lay, "spatial")
+        strat = strategy_of(name)
+        g = O.build_graph(lay, strat)
         V = g["num_node"]
         sd = O.det_state(3, ncls, g["A"], True)
         x, labels = model_inputs(ci)
-        m = RefModel(3, ncls, dict(layout=lay, strategy="spatial"), True)
+        m = RefModel(3, ncls, dict(layout=lay, strategy=strat), True)
         m.double()
         missing = m.load_state_dict(sd, strict=True)
         m.train(training)
@@ -202,8 +204,33 @@ def gen_sgd():
     print("sgd: 3 steps ok, losses", [float(out["loss%d" % i]) for i in range(3)])
 
 
+def gen_feeder():
+    """feeder/tools.py of the reference on closed-form clips, with the module-level generators it draws from
+    (random, numpy.random) seeded per case: the tests hand the same seeds to random.Random / numpy RandomState."""
+    import random
+    import feeder.tools as RT
+    out = {}
+    for name, fn, shape, gap, kw, s_py, s_np in FEEDER_CASES:
+        d = feeder_clip(name, shape, gap)
+        random.seed(s_py)
+        np.random.seed(s_np)
+        if fn == "pipeline":
+            r = RT.random_move(np.array(RT.random_choose(d.copy(), kw["size"])))
+        else:
+            r = getattr(RT, fn)(d.copy(), **kw)
+        out[name] = np.zeros(0) if r is None else np.asarray(r, dtype=np.float64)
+    np.savez_compressed(os.path.join(HERE, "feeder.npz"), **out)
+    print("feeder: %d cases" % len(out))
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
+    if len(sys.argv) > 1:                      # e.g. `make_golden.py feeder model`: regenerate only those files
+        for what in sys.argv[1:]:
+            {"graph": gen_graphs, "gcn": gen_gcn, "block": gen_block, "model": gen_model, "sgd": gen_sgd,
+             "feeder": gen_feeder}[what]()
+        sys.exit(0)
+    gen_feeder()
     gen_graphs()
     gen_gcn()
     gen_block()

@@ -21,6 +21,68 @@ from stgcn_rt import checkpoint as CK                       # noqa: E402
 from stgcn_rt.evaluate import evaluate, topk_accuracy       # noqa: E402
 
 
+from tests.golden import cases as GC                        # noqa: E402
+
+_GOLD = np.load(os.path.join(ROOT, "tests", "golden", "feeder.npz"))
+
+
+def _ours(fn, d, kw, s_py, s_np):
+    """Our feeder.tools function on clip d with the generators the reference drew from, seeded alike."""
+    rng, nprng = random.Random(s_py), np.random.RandomState(s_np)
+    if fn == "random_choose":
+        return tools.random_choose(d, kw["size"], kw.get("auto_pad", True), rng=rng)
+    if fn == "auto_pading":
+        return tools.auto_pading(d, kw["size"], kw.get("random_pad", False), rng=rng)
+    if fn == "random_move":
+        return tools.random_move(d, rng=rng, nprng=nprng, **{k: tuple(v) for k, v in kw.items()})
+    if fn == "random_shift":
+        return tools.random_shift(d, rng=rng)
+    if fn == "downsample":
+        return tools.downsample(d, kw["step"], kw.get("random_sample", True), rng=nprng)
+    if fn == "mean_subtractor":
+        return tools.mean_subtractor(d, kw["mean"])
+    if fn == "pipeline":
+        return tools.random_move(np.array(tools.random_choose(d, kw["size"], rng=rng)), rng=rng, nprng=nprng)
+    raise KeyError(fn)
+
+
+@pytest.mark.parametrize("case", GC.FEEDER_CASES, ids=[c[0] for c in GC.FEEDER_CASES])
+def test_tools_match_reference_fixtures(case):
+    """feeder.tools against the outputs of the reference's feeder/tools.py (tests/golden/feeder.npz, written by
+    tests/golden/make_golden.py with `random` / `numpy.random` seeded per case)."""
+    name, fn, shape, gap, kw, s_py, s_np = case
+    d = GC.feeder_clip(name, shape, gap)
+    got = _ours(fn, d.copy(), kw, s_py, s_np)
+    want = _GOLD[name]
+    if want.size == 0:
+        assert got is None
+        return
+    assert got.shape == want.shape
+    if fn in ("random_move", "pipeline"):
+        assert np.abs(got - want).max() < 1e-12            # same formula, products summed in another order
+    else:
+        assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("case", [c for c in GC.FEEDER_CASES if c[1] in ("random_choose", "random_move", "pipeline")],
+                         ids=lambda c: c[0])
+def test_feeder_oracle_matches_reference_fixtures(case):
+    """The augmentation oracle (window / move with the draws passed in) reproduces the reference's outputs when it
+    is handed the draws the reference made."""
+    name, fn, shape, gap, kw, s_py, s_np = case
+    d = GC.feeder_clip(name, shape, gap)
+    rng, nprng = random.Random(s_py), np.random.RandomState(s_np)
+    out = d
+    if fn in ("random_choose", "pipeline"):
+        shift = tools.choose_shift(shape[1], kw["size"], kw.get("auto_pad", True), rng=rng)
+        if shift is not None:
+            out = FO.window(out, kw["size"], shift)
+    if fn in ("random_move", "pipeline"):
+        mk = {k: tuple(v) for k, v in kw.items() if k != "size"}
+        out = FO.move(out, *tools.move_params(out.shape[1], rng=rng, nprng=nprng, **mk))
+    assert out.shape == _GOLD[name].shape and np.abs(out - _GOLD[name]).max() < 1e-12
+
+
 def clip(C=3, T=20, V=5, M=2, seed=0):
     return np.random.RandomState(seed).randn(C, T, V, M)
 
@@ -67,8 +129,6 @@ def test_move_matches_oracle():
 def test_other_tools():
     d = clip(T=12)
     assert tools.downsample(d, 3, random_sample=False).shape == (3, 4, 5, 2)
-    ts = tools.temporal_slice(d, 3)
-    assert ts.shape == (3, 4, 5, 6) and np.array_equal(ts[:, 1, :, 2:4], d[:, 4])
     z = np.zeros((3, 12, 5, 2)); z[:, 2:7] = d[:, 2:7]
     sh = tools.random_shift(z, rng=random.Random(4))
     bias = random.Random(4).randint(0, 12 - 5)
@@ -174,6 +234,50 @@ def test_evaluate_and_topk():
     ce = torch.nn.CrossEntropyLoss()
     assert out["mean_loss"] == pytest.approx(np.mean([ce(full[:6], ys[:6]).item(), ce(full[6:], ys[6:]).item()]), rel=1e-5)
     assert out["topk"][3] == 1.0 and out["topk"][1] == pytest.approx((full.argmax(1) == ys).float().mean().item())
+
+
+def test_item_with_draws_is_getitem_unapplied(tmp_path):
+    N, T, W = 4, 20, 12
+    data = np.random.RandomState(3).randn(N, 3, T, 5, 2).astype(np.float32)
+    np.save(tmp_path / "d.npy", data)
+    with open(tmp_path / "l.pkl", "wb") as f:
+        pickle.dump((["a"] * N, list(range(N))), f)
+    fd = Feeder(str(tmp_path / "d.npy"), str(tmp_path / "l.pkl"), random_choose=True, random_move=True, window_size=W)
+    for i in range(N):
+        random.seed(40 + i); np.random.seed(50 + i)
+        want, lab = fd[i]
+        raw, lab2, shift, move = fd.item_with_draws(i, rng=random.Random(40 + i), nprng=np.random.RandomState(50 + i))
+        assert lab == lab2 and np.array_equal(raw, data[i])
+        got = FO.move(FO.window(raw.astype(np.float64), W, shift), *move)
+        assert np.abs(got - want).max() < 1e-6
+    fp = Feeder(str(tmp_path / "d.npy"), str(tmp_path / "l.pkl"), window_size=30)
+    raw, _, shift, move = fp.item_with_draws(0)
+    assert shift == 0 and move is None and np.array_equal(FO.window(raw, 30, 0), fp[0][0])
+
+
+@pytest.mark.gpu
+def test_augment_batch_gpu_matches_reference_fixtures():
+    """stgcn_augment (window + move for a batch in one launch) against the reference's Feeder.__getitem__ pipeline
+    outputs (tests/golden/feeder.npz `pipeline_*`, `choose_*`, `move_*`), draws reproduced from the recorded seeds."""
+    from stgcn_rt import ops as P
+    for name, fn, shape, gap, kw, s_py, s_np in GC.FEEDER_CASES:
+        if fn not in ("pipeline", "random_choose", "random_move"):
+            continue
+        d = GC.feeder_clip(name, shape, gap)
+        rng, nprng = random.Random(s_py), np.random.RandomState(s_np)
+        shift, move, W = None, None, shape[1]
+        if fn in ("pipeline", "random_choose"):
+            shift = tools.choose_shift(shape[1], kw["size"], kw.get("auto_pad", True), rng=rng)
+            if shift is not None:
+                W = kw["size"]
+        if fn in ("pipeline", "random_move"):
+            mk = {k: tuple(v) for k, v in kw.items() if k != "size"}
+            move = tuple(np.asarray(v)[None] for v in tools.move_params(W, rng=rng, nprng=nprng, **mk))
+        xd = torch.from_numpy(d.astype(np.float32))[None].cuda()
+        got = P.augment_batch(xd, window=W, shift=None if shift is None else [shift], move=move)[0].cpu().numpy()
+        want = _GOLD[name]
+        assert got.shape == want.shape, name
+        assert np.abs(got - want).max() < 2e-6 * max(1.0, np.abs(want).max()), (name, np.abs(got - want).max())
 
 
 @pytest.mark.gpu

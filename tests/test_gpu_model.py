@@ -164,10 +164,11 @@ def test_model(net, golden, ci, dtype):
     only a few thousand rows per channel one such element moves a gradient by about 1e-3)."""
     mod, _ = net
     name, lay, ncls, N, T, M, training = C.MODEL_CASES[ci]
-    g = O.build_graph(lay, "spatial")
+    strat = C.strategy_of(name)
+    g = O.build_graph(lay, strat)
     sd = O.det_state(3, ncls, g["A"], True, dtype=torch.float32)
     x, labels = C.model_inputs(ci)
-    m = mod.Model(3, ncls, dict(layout=lay, strategy="spatial"), True, compute_dtype=dtype).to(DEV)
+    m = mod.Model(3, ncls, dict(layout=lay, strategy=strat), True, compute_dtype=dtype).to(DEV)
     m.load_state_dict(sd, strict=True)
     m.train(training)
     F = _capture() if training else None

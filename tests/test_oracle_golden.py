@@ -78,9 +78,18 @@ def test_model_full_ntu(golden, ci):
     _check_model(golden, ci)
 
 
+_K12 = [i for i, c in enumerate(C.MODEL_CASES) if C.strategy_of(c[0]) != "spatial"]
+
+
+@pytest.mark.parametrize("ci", _K12, ids=[C.MODEL_CASES[i][0] for i in _K12])
+def test_model_uniform_distance(golden, ci):
+    """K = 1 / 2 partitions (uniform / distance strategies, graph.py:85-94 of the reference)."""
+    _check_model(golden, ci)
+
+
 def _check_model(golden, ci):
     name, lay, ncls, N, T, M, training = C.MODEL_CASES[ci]
-    g = O.build_graph(lay, "spatial")
+    g = O.build_graph(lay, C.strategy_of(name))
     sd = O.det_state(3, ncls, g["A"], True)
     x, labels = C.model_inputs(ci)
     logits, cache, newb = O.model_forward(sd, x, training)

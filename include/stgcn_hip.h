@@ -95,10 +95,13 @@ int stgcn_stats_to_grads(const double* stats, float* dgamma, float* dbeta, int C
  * relu_mask (optional, 2 bytes per 16-byte piece of out: rows*C/4 bytes for bf16, rows*C/2 for f32): bit j set when
  * element j of the piece is positive, bit 8+j when dropout kept it -- the backward then reads 1/8 of the bytes of
  * out and evaluates no dropout hash.
+ * seed_step (optional, device memory): a step counter the caller advances on the device; the launch then draws with
+ * seed + (*seed_step) * 0x85EBCA6B (mod 2^32; only the low 32 bits of the counter are read, so it may be an int64).
+ * A step replayed from a captured HIP graph thus draws a fresh mask every replay although `seed` is frozen in it.
  * Replaces: BatchNorm2d apply + Dropout + residual add + ReLU (net/st_gcn.py:169-170, 193-197). */
 int stgcn_block_out_fwd(int dtype, const void* o, const void* res, void* out, void* relu_mask,
                         const float* scale2, const float* shift2, const float* res_scale, const float* res_shift,
-                        size_t rows, int C, float drop_p, uint32_t seed, void* stream);
+                        size_t rows, int C, float drop_p, uint32_t seed, const uint32_t* seed_step, void* stream);
 
 /* Backward of the stage above.  pass 0: per-channel sums (stats2, statsr).  pass 1: dO (BatchNorm backward of the
  * main branch), dR (same for a conv residual), g (= masked incoming gradient, for an identity residual), the
@@ -166,6 +169,10 @@ int stgcn_probe_tr16(short* out, void* stream);
 int stgcn_version(void);
 const char* stgcn_arch(void);
 int stgcn_device_count(void);
+/* What the launchers have learnt / set for device ordinal `device` so far (both kept per device: a process may drive
+ * several GPUs, as the reference's nn.DataParallel does, processor/io.py:86-87): its compute-unit count (0 = not
+ * asked yet) and how many kernels have opted in to more than 64 KiB of LDS there. */
+int stgcn_launch_state(int device, int* num_cus, int* lds_opt_ins);
 
 #ifdef __cplusplus
 }

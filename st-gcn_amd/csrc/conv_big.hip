@@ -385,11 +385,11 @@ static int launch_conv_big(ConvBigArgs& a, hipStream_t stream) {
     a.zero_row = (int)((body + CB_RS - 1) / CB_RS);
     const size_t lds = (size_t)(a.zero_row + 1) * CB_RS;
     const int nct = ceil_div_i(a.Cout, BN);
-    int gx = max(1, 256 / nct);
+    int gx = max(1, stgcn_num_cus() / nct);
     if (gx > a.B * a.tiles_per_sample) gx = a.B * a.tiles_per_sample;
     auto kern = conv_big_kernel<T, WR, WC, MT, NT, EPI>;
-    static bool set = false;
-    if (!set) { if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return STGCN_ERR_LAUNCH; set = true; }
+    static std::atomic<uint64_t> lds_ok{0};
+    if (stgcn_allow_big_lds((const void*)kern, lds_ok) != STGCN_OK) return STGCN_ERR_LAUNCH;
     hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)nct), dim3(WR * WC * 64), lds, stream, a);
     return hipGetLastError() == hipSuccess ? STGCN_OK : STGCN_ERR_LAUNCH;
 }

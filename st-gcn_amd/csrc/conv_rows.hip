@@ -248,11 +248,8 @@ static int launch_conv_rows(ConvRowsArgs& a, hipStream_t stream) {
     a.tiles_per_sample = ceil_div_i(a.Tout * a.V, BM);
     dim3 grid((unsigned)(a.B * a.tiles_per_sample), (unsigned)ceil_div_i(a.Cout, BN));
     auto kern = conv_rows_kernel<T, WM, NT, EPI>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return STGCN_ERR_LAUNCH;
-        attr_set = true;
-    }
+    static std::atomic<uint64_t> lds_ok{0};
+    if (stgcn_allow_big_lds((const void*)kern, lds_ok) != STGCN_OK) return STGCN_ERR_LAUNCH;
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, a);
     return hipGetLastError() == hipSuccess ? STGCN_OK : STGCN_ERR_LAUNCH;
 }

@@ -278,7 +278,7 @@ static int launch_conv_t9(ConvT9Args& a, hipStream_t stream) {
     const int gy = ceil_div_i(a.Cout, 64);
     // one workgroup per CU is resident (LDS): aim at one round of 256 workgroups, so the per-workgroup start-up
     // (weight load, first window) is paid once per CU
-    int segs = (256 + a.B * gy - 1) / (a.B * gy);
+    int segs = (stgcn_num_cus() + a.B * gy - 1) / (a.B * gy);
     if (segs < 1) segs = 1;
     if (segs > ntiles) segs = ntiles;
     int tps = ceil_div_i(ntiles, segs);
@@ -287,8 +287,8 @@ static int launch_conv_t9(ConvT9Args& a, hipStream_t stream) {
     a.tiles_per_seg = tps;
     a.segs_per_sample = segs;
     auto kern = conv_t9_kernel<EPI>;
-    static bool set = false;
-    if (!set) { if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return STGCN_ERR_LAUNCH; set = true; }
+    static std::atomic<uint64_t> lds_ok{0};
+    if (stgcn_allow_big_lds((const void*)kern, lds_ok) != STGCN_OK) return STGCN_ERR_LAUNCH;
     hipLaunchKernelGGL(kern, dim3((unsigned)(a.B * segs), (unsigned)gy), dim3(T9_NT), lds, stream, a);
     return hipGetLastError() == hipSuccess ? STGCN_OK : STGCN_ERR_LAUNCH;
 }

@@ -516,7 +516,7 @@ static int conv_wgrad_ring_try(const void* in, const void* dout, float* dW, cons
     else { const int ot = 128 / V; a.tile_rows = ot * V; ntiles = ceil_div_i(Tout, ot); }
     a.tiles_per_sample = ntiles;
     const int ncot = ceil_div_i(Cout, 64), ncit = Cin / 64;
-    int nwg = 256 / (ncot * ncit);
+    int nwg = stgcn_num_cus() / (ncot * ncit);
     if (nwg < 1) nwg = 1;
     const size_t per_part = (size_t)ntaps * Cout * Cin * sizeof(float);
     while (nwg > 1 && (size_t)nwg * per_part > ws_bytes) nwg /= 2;
@@ -532,8 +532,8 @@ static int conv_wgrad_ring_try(const void* in, const void* dout, float* dW, cons
     const int variant = (stride - 1) * 2 + (ntaps == 9 ? 1 : 0);
     const void* fns[4] = {(const void*)conv_wgrad_ring_kernel<1, 1>, (const void*)conv_wgrad_ring_kernel<1, 9>,
                           (const void*)conv_wgrad_ring_kernel<2, 1>, (const void*)conv_wgrad_ring_kernel<2, 9>};
-    static bool set[4] = {false, false, false, false};
-    if (!set[variant]) { if (hipFuncSetAttribute(fns[variant], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return STGCN_ERR_LAUNCH; set[variant] = true; }
+    static std::atomic<uint64_t> lds_ok[4];
+    if (stgcn_allow_big_lds(fns[variant], lds_ok[variant]) != STGCN_OK) return STGCN_ERR_LAUNCH;
     const dim3 grid((unsigned)nwg, (unsigned)ncot, (unsigned)ncit);
     switch (variant) {
         case 0: hipLaunchKernelGGL((conv_wgrad_ring_kernel<1, 1>), grid, dim3(512), lds, stream, a); break;
@@ -572,8 +572,8 @@ static int conv_wgrad_run(ConvWgradArgs& a, float* dW, size_t ws_bytes, hipStrea
     if (npw > 12) return STGCN_ERR_ARG;
 #define CW_LAUNCH(MT_, NP_, EX_) do { \
         auto kern = conv_wgrad_kernel<T, MT_, NP_, EX_>; \
-        static bool set_ = false; \
-        if (!set_) { if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return STGCN_ERR_LAUNCH; set_ = true; } \
+        static std::atomic<uint64_t> lds_ok_{0}; \
+        if (stgcn_allow_big_lds((const void*)kern, lds_ok_) != STGCN_OK) return STGCN_ERR_LAUNCH; \
         hipLaunchKernelGGL(kern, grid, dim3(512), lds, stream, a); } while (0)
     if (a.ntaps == 1) {
         if (npw <= 6) CW_LAUNCH(1, 6, true); else CW_LAUNCH(1, 12, true);

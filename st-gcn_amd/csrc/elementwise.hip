@@ -133,6 +133,7 @@ struct BlockOutArgs {
     const float* s2; const float* b2; const float* sr; const float* br;
     uint16_t* mask;      // optional: two bytes per 16-byte piece: bit j = (element j > 0), bit 8+j = (element j kept by dropout)
     size_t rows; int C; uint32_t seed, thr; float keep_scale;
+    const uint32_t* seed_step;   // optional device counter mixed into the seed (see stgcn_block_out_fwd)
 };
 
 template <typename T>
@@ -140,6 +141,7 @@ __global__ __launch_bounds__(256) void block_out_fwd_kernel(BlockOutArgs a) {
     constexpr int VEC = ET<T>::VEC;
     RowMap<T> m(a.C);
     if (!m.active) return;
+    if (a.thr && a.seed_step) a.seed += *a.seed_step * STGCN_SEED_STEP_MUL;
     float s2[VEC], b2[VEC], sr[VEC], br[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
@@ -196,9 +198,10 @@ static inline uint32_t drop_thr(float p) {
 
 extern "C" int stgcn_block_out_fwd(int dtype, const void* o, const void* res, void* out, void* relu_mask,
                                    const float* scale2, const float* shift2, const float* res_scale, const float* res_shift,
-                                   size_t rows, int C, float drop_p, uint32_t seed, void* stream) {
+                                   size_t rows, int C, float drop_p, uint32_t seed, const uint32_t* seed_step, void* stream) {
     if (!o || !out || !scale2 || !shift2 || drop_p < 0.f || drop_p >= 1.f) return STGCN_ERR_ARG;
     BlockOutArgs a;
+    a.seed_step = seed_step;
     a.o = o; a.res = res; a.out = out; a.mask = (uint16_t*)relu_mask; a.s2 = scale2; a.b2 = shift2; a.sr = res_scale; a.br = res_shift;
     a.rows = rows; a.C = C; a.seed = seed; a.thr = drop_thr(drop_p); a.keep_scale = 1.f / (1.f - drop_p);
     if (dtype == STGCN_BF16) {
@@ -861,6 +864,12 @@ extern "C" int stgcn_pack_weights(int dtype, const void* table, int ndesc, size_
 extern "C" int stgcn_version(void) { return 1; }
 extern "C" const char* stgcn_arch(void) { return "gfx950"; }
 extern "C" int stgcn_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return -1; return n; }
+extern "C" int stgcn_launch_state(int device, int* num_cus, int* lds_opt_ins) {
+    if (device < 0 || device >= STGCN_MAX_DEV) return STGCN_ERR_ARG;
+    if (num_cus) *num_cus = g_stgcn_cus[device].load(std::memory_order_relaxed);
+    if (lds_opt_ins) *lds_opt_ins = g_stgcn_attr_sets[device].load(std::memory_order_relaxed);
+    return STGCN_OK;
+}
 
 // Diagnostic: what ds_read_b64_tr_b16 hands each lane for a [32 rows][32 x 16-bit] LDS image whose
 // element (row, col) holds the raw pattern row*256 + col, addressed exactly as the wgrad kernels do.

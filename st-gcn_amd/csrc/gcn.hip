@@ -313,8 +313,8 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : (NA >= 1 && NA <= 4 && (!A
 template <typename T, int NA, bool ADD, int NWV>
 static int gcn_fused_launch3(GcnFusedArgs& a, dim3 grid, size_t lds, hipStream_t stream) {
     auto kern = gcn_fused_kernel<T, NA, ADD, NWV>;
-    static bool set = false;
-    if (!set) { if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return STGCN_ERR_LAUNCH; set = true; }
+    static std::atomic<uint64_t> lds_ok{0};
+    if (stgcn_allow_big_lds((const void*)kern, lds_ok) != STGCN_OK) return STGCN_ERR_LAUNCH;
     hipLaunchKernelGGL(kern, grid, dim3(NWV * 64), lds, stream, a);
     return hipGetLastError() == hipSuccess ? STGCN_OK : STGCN_ERR_LAUNCH;
 }
@@ -351,7 +351,7 @@ static int gcn_fused_run(GcnFusedArgs& a, hipStream_t stream) {
     const int gy = ceil_div_i(a.Nout, ntw * 32);
     // persistent waves: as many workgroups as stay resident (2 per CU when the LDS image allows it)
     const int per_cu = ((!a.add || ET<T>::IS_BF16) && na >= 1 && na <= 4 && 3 * lds <= 160 * 1024) ? 3 : lds <= 80 * 1024 ? 2 : 1;
-    const int resident = per_cu * 256;
+    const int resident = per_cu * stgcn_num_cus();
     int gx = max(1, resident / gy);
     if (gx > ceil_div_i(a.NF, nwv)) gx = ceil_div_i(a.NF, nwv);
     const dim3 grid((unsigned)gx, (unsigned)gy);
@@ -601,8 +601,8 @@ __global__ __launch_bounds__(256) void sum_parts_wave_kernel(const float* slab, 
 template <typename T, int NA, int NWV>
 static int gcn_agrad_launch2(GcnAgradArgs& a, dim3 grid, size_t lds, hipStream_t stream) {
     auto kern = gcn_agrad_kernel<T, NA, NWV>;
-    static bool set = false;
-    if (!set) { if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return STGCN_ERR_LAUNCH; set = true; }
+    static std::atomic<uint64_t> lds_ok{0};
+    if (stgcn_allow_big_lds((const void*)kern, lds_ok) != STGCN_OK) return STGCN_ERR_LAUNCH;
     hipLaunchKernelGGL(kern, grid, dim3(NWV * 64), lds, stream, a);
     return hipGetLastError() == hipSuccess ? STGCN_OK : STGCN_ERR_LAUNCH;
 }
@@ -635,7 +635,7 @@ static int gcn_agrad_run(GcnAgradArgs& a, float* dA, size_t ws_bytes, hipStream_
     if (lds > 160 * 1024) return STGCN_ERR_ARG;
     a.ntw = ntw;
     const int gy = ceil_div_i(a.Cout, ntw * 32);
-    const int resident = (lds <= 80 * 1024 ? 2 : 1) * 256;
+    const int resident = (lds <= 80 * 1024 ? 2 : 1) * stgcn_num_cus();
     int gx = max(1, resident / gy);
     if (gx > ceil_div_i(a.NF, nwv)) gx = ceil_div_i(a.NF, nwv);
     const size_t n = (size_t)a.K * a.V * a.V;
@@ -1065,7 +1065,7 @@ static int gcn_wgrad_wide_try(const void* x, const void* dy, const float* adj, f
     const int gy = ceil_div_i(Cout, 64);
     // as many workgroups as stay resident: narrow inputs run few waves per workgroup and leave LDS for three
     const int per_cu = nt <= 384 && 3 * lds <= 160 * 1024 ? 3 : nt <= 512 && 2 * lds <= 160 * 1024 ? 2 : 1;
-    int gx = max(1, per_cu * 256 / gy);
+    int gx = max(1, per_cu * stgcn_num_cus() / gy);
     const size_t nW = (size_t)K * Cout * Cin, nB = (size_t)K * Cout;
     while (gx > 1 && (size_t)gx * (nW + nB) * sizeof(float) > ws_bytes) gx /= 2;
     if ((size_t)gx * (nW + nB) * sizeof(float) > ws_bytes) return STGCN_ERR_WORKSPACE;
@@ -1077,9 +1077,9 @@ static int gcn_wgrad_wide_try(const void* x, const void* dy, const float* adj, f
     a.part_stride = nW + nB;
     a.slabB = a.slabW + nW;                               // bias sums follow the weight sums inside every partial
     const void* fn = a.nci == 1 ? (const void*)gcn_wgrad_wide_kernel<1> : a.nci == 2 ? (const void*)gcn_wgrad_wide_kernel<2> : (const void*)gcn_wgrad_wide_kernel<4>;
-    static bool set[3] = {false, false, false};
+    static std::atomic<uint64_t> lds_ok[3];
     const int si = a.nci == 1 ? 0 : a.nci == 2 ? 1 : 2;
-    if (!set[si]) { if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return STGCN_ERR_LAUNCH; set[si] = true; }
+    if (stgcn_allow_big_lds(fn, lds_ok[si]) != STGCN_OK) return STGCN_ERR_LAUNCH;
     const dim3 grid((unsigned)gx, (unsigned)gy), block((unsigned)nt);
     if (a.nci == 1) hipLaunchKernelGGL(gcn_wgrad_wide_kernel<1>, grid, block, lds, stream, a);
     else if (a.nci == 2) hipLaunchKernelGGL(gcn_wgrad_wide_kernel<2>, grid, block, lds, stream, a);
@@ -1103,7 +1103,7 @@ static int gcn_wgrad_run(GcnWgradArgs& a, float* dW, float* db, size_t ws_bytes,
     size_t lds = (size_t)4 * (32 * drs + 32 * xrs) + tabb;
     if (lds < 16 * 1024) lds = 16 * 1024;
     const int ncot = ceil_div_i(a.Cout, 32), ncig = a.Cin / cig;
-    int gx = 768 / (ncot * ncig);
+    int gx = 3 * stgcn_num_cus() / (ncot * ncig);
     if (gx < 1) gx = 1;
     const int fgroups = ceil_div_i(a.NF, 4);
     if (gx > fgroups) gx = fgroups;
@@ -1113,8 +1113,8 @@ static int gcn_wgrad_run(GcnWgradArgs& a, float* dW, float* db, size_t ws_bytes,
     a.iters = ceil_div_i(fgroups, gx);
     a.slabB = a.slabW + (size_t)gx * nW;
     auto kern = gcn_wgrad_kernel<T>;
-    static bool set = false;
-    if (!set) { if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return STGCN_ERR_LAUNCH; set = true; }
+    static std::atomic<uint64_t> lds_ok{0};
+    if (stgcn_allow_big_lds((const void*)kern, lds_ok) != STGCN_OK) return STGCN_ERR_LAUNCH;
     hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)ncot, (unsigned)ncig), dim3(256), lds, stream, a);
     if (hipGetLastError() != hipSuccess) return STGCN_ERR_LAUNCH;
     hipLaunchKernelGGL(sum_parts_kernel, dim3(slab_sum_grid(nW)), dim3(256), 0, stream, a.slabW, dW, gx, nW);

@@ -9,6 +9,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 
 #define STGCN_OK 0
 #define STGCN_ERR_ARG 1
@@ -106,6 +107,8 @@ __device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >
 // Dropout keep decisions.  One 32-bit hash serves the two elements 2q and 2q+1 of the flat channels-last tensor:
 // its low half decides the even one, its high half the odd one, each kept when its 16 bits are >= thr16
 // (= round(p * 65536), so p is honoured to 1/65536).
+// A launch whose seed comes with a device-side step counter uses seed + counter * STGCN_SEED_STEP_MUL (mod 2^32).
+#define STGCN_SEED_STEP_MUL 0x85EBCA6Bu
 __device__ __forceinline__ uint32_t drop_hash(uint64_t pair, uint32_t seed) {
     uint32_t x = (uint32_t)pair ^ seed;
     x += (uint32_t)(pair >> 32) * 0x9E3779B9u;
@@ -134,6 +137,39 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 __device__ __forceinline__ i32x4 zero16() { i32x4 z = {0, 0, 0, 0}; return z; }
 
 static inline int ceil_div_i(int a, int b) { return (a + b - 1) / b; }
+
+// ---- per-device launch state -------------------------------------------------------------------------------------
+// A process may drive several GPUs (one host thread per device, or one thread switching devices).  Whatever a
+// launcher learns or sets about "the device" is therefore kept per device ordinal, behind atomics so that the first
+// calls of two host threads may race: both then do the same idempotent work.
+constexpr int STGCN_MAX_DEV = 64;
+inline std::atomic<int> g_stgcn_cus[STGCN_MAX_DEV];          // compute units of device d (0 = not asked yet)
+inline std::atomic<int> g_stgcn_attr_sets[STGCN_MAX_DEV];    // diagnostics: large-LDS opt-ins done on device d
+
+static inline int stgcn_cur_device() { int d = 0; if (hipGetDevice(&d) != hipSuccess) d = 0; return d; }
+
+// Compute units of the current device (MI355X: 256); grids of the persistent kernels are sized from it.
+static inline int stgcn_num_cus() {
+    const int d = stgcn_cur_device();
+    const bool slot = d >= 0 && d < STGCN_MAX_DEV;
+    int c = slot ? g_stgcn_cus[d].load(std::memory_order_relaxed) : 0;
+    if (c <= 0) {
+        if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess || c <= 0) c = 256;
+        if (slot) g_stgcn_cus[d].store(c, std::memory_order_relaxed);
+    }
+    return c;
+}
+
+// Kernels that use more than 64 KiB of dynamic LDS must opt in with hipFuncSetAttribute, and the attribute belongs to
+// the (function, device) pair.  `done` is the launcher's own bit set of devices already served (bit d = ordinal d).
+static inline int stgcn_allow_big_lds(const void* fn, std::atomic<uint64_t>& done) {
+    const int d = stgcn_cur_device();
+    const uint64_t bit = (d >= 0 && d < STGCN_MAX_DEV) ? (1ull << d) : 0ull;
+    if (bit && (done.load(std::memory_order_acquire) & bit)) return STGCN_OK;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return STGCN_ERR_LAUNCH;
+    if (bit) { done.fetch_or(bit, std::memory_order_release); g_stgcn_attr_sets[d].fetch_add(1, std::memory_order_relaxed); }
+    return STGCN_OK;
+}
 
 // Fixed-order reduction of a partial-sum slab [nparts][n] (f32) in one launch.  A workgroup of 256 threads is
 // 64 consecutive elements x 4 part groups: thread (o = tid & 63, g = tid >> 6) adds parts g, g+4, g+8, ... of element

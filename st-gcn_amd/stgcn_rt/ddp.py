@@ -5,7 +5,7 @@ Replaces the reference's nn.DataParallel wrap (processor/io.py:86-87 of hensyou/
 one process per GPU: every rank holds a full replica, runs the model on its own shard of the
 batch (BatchNorm statistics stay per replica, as under DataParallel), and gradients are
 averaged with a few large all-reduces over RCCL/xGMI.  Buckets follow reverse execution order
-(fcn, block 9 ... block 0, data_bn) and each is launched as soon as its last gradient has been
+(fcn, block 9 ... block 0, the edge importances, data_bn) and each is launched as soon as its last gradient has been
 accumulated, so communication overlaps the rest of backward.  The optimizer step is one HIP
 kernel over the flat buffers (torch.optim.SGD semantics: processor/recognition.py:46-53).
 """
@@ -60,7 +60,10 @@ class FlatParams:
 
 
 def reverse_execution_order(model):
-    """Parameter order in which gradients become ready: fcn, block 9 ... block 0, data_bn."""
+    """Parameter order in which gradients become ready: fcn, block 9 ... block 0, then every edge_importance, then
+    data_bn.  The importances come last although each belongs to one block: A * importance is ONE autograd node for
+    all blocks (functional.EdgeImportanceFn), whose backward runs only after block 0's -- spread over the blocks'
+    buckets they would hold every bucket back until the end of backward."""
     def order(params):
         ids = {id(p) for p in params}
         out = []
@@ -69,11 +72,12 @@ def reverse_execution_order(model):
                 if id(p) in ids and all(p is not q for q in out):
                     out.append(p)
         take(model.fcn)
-        ei = getattr(model, "edge_importance", None)
         for i in reversed(range(len(model.st_gcn_networks))):
             take(model.st_gcn_networks[i])
-            if isinstance(ei, torch.nn.ParameterList):
-                if all(ei[i] is not q for q in out):
+        ei = getattr(model, "edge_importance", None)
+        if isinstance(ei, torch.nn.ParameterList):
+            for i in reversed(range(len(ei))):
+                if id(ei[i]) in ids and all(ei[i] is not q for q in out):
                     out.append(ei[i])
         take(model.data_bn)
         for p in params:                      # anything not covered above
@@ -110,6 +114,7 @@ class GradBucketer:
         self.pending = [0] * len(self.buckets)
         self.handles = []
         self.launched = []
+        self.trace = []                       # ("grad", param index) / ("launch", bucket) in the order they happened
         if self.world > 1:
             for i, p in enumerate(flat.params):
                 p.register_post_accumulate_grad_hook(self._make_hook(i))
@@ -119,10 +124,12 @@ class GradBucketer:
         self.pending = [len(idx) for (_, _, idx) in self.buckets]
         self.handles = []
         self.launched = []
+        self.trace = []
 
     def _make_hook(self, i):
         def hook(param):
             b = self.bucket_of[i]
+            self.trace.append(("grad", i))
             self.pending[b] -= 1
             if self.pending[b] == 0:
                 self._launch(b)
@@ -131,6 +138,7 @@ class GradBucketer:
     def _launch(self, b):
         s, e, idxs = self.buckets[b]
         self.launched.append(b)
+        self.trace.append(("launch", b))
         self.flat.gather(idxs)
         self.handles.append(dist.all_reduce(self.flat.grad[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 

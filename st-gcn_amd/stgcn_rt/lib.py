@@ -27,7 +27,7 @@ _SIGS = {
     "stgcn_gcn_wgrad": [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp],
     "stgcn_bn_finalize": [_vp, _d, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _i, _i, _vp],
     "stgcn_stats_to_grads": [_vp, _vp, _vp, _i, _vp],
-    "stgcn_block_out_fwd": [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _f, _u32, _vp],
+    "stgcn_block_out_fwd": [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _f, _u32, _vp, _vp],
     "stgcn_block_out_bwd": [_i, _i, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                             _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _f, _u32, _d, _i, _vp],
     "stgcn_bn_bwd_apply": [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _d, _vp, _vp, _sz, _i, _i, _vp],
@@ -44,6 +44,7 @@ _SIGS = {
     "stgcn_probe_tr16": [_vp, _vp],
     "stgcn_version": [],
     "stgcn_device_count": [],
+    "stgcn_launch_state": [_i, _vp, _vp],
 }
 
 EXPORTS = tuple(_SIGS) + ("stgcn_arch",)

@@ -291,15 +291,19 @@ def stats_to_grads(stats, Cc):
     return dg, dbt
 
 
-def block_out_fwd(o, res, bn2, bnr, drop_p, seed, want_mask=False):
+SEED_STEP_MUL = 0x85EBCA6B
+
+
+def block_out_fwd(o, res, bn2, bnr, drop_p, seed, want_mask=False, seed_step=None):
     """-> out, or (out, mask) with want_mask: 16 bits per 16-byte piece of out, bit j = element j positive, bit 8+j =
-    element j kept by dropout."""
+    element j kept by dropout.  seed_step: optional integer tensor on the device (a step counter); the kernel draws
+    with seed + seed_step * SEED_STEP_MUL (mod 2^32)."""
     B, Cc, T, V = o.shape
     out = new_act(B, Cc, T, V, o.dtype, o.device)
     mask = torch.empty((B * T * V * Cc * o.element_size() // 16,), dtype=torch.int16, device=o.device) if want_mask else None
     _launch((str(o.dtype), B * T * V, Cc, res is not None, bnr is not None), "stgcn_block_out_fwd", L.dtype_code(o.dtype), L.ptr(o), L.ptr(res), L.ptr(out), L.ptr(mask), L.ptr(bn2.scale), L.ptr(bn2.shift),
            L.ptr(bnr.scale) if bnr is not None else None, L.ptr(bnr.shift) if bnr is not None else None,
-           B * T * V, Cc, float(drop_p), int(seed) & 0xFFFFFFFF, L.stream_ptr())
+           B * T * V, Cc, float(drop_p), int(seed) & 0xFFFFFFFF, L.ptr(seed_step), L.stream_ptr())
     return (out, mask) if want_mask else out
 
 

@@ -30,6 +30,26 @@ def test_library_exports_every_declared_symbol():
     assert l.stgcn_version() >= 1 and l.stgcn_arch() == b"gfx950"
 
 
+def test_launch_state_is_kept_per_device():
+    """Compute-unit counts and the large-LDS opt-ins are tables over device ordinals (a process may drive several
+    GPUs, as nn.DataParallel does: processor/io.py:86-87 of the reference), not process-wide flags."""
+    from stgcn_rt import lib
+    l = lib.load()
+    cus, opt = ctypes.c_int(-1), ctypes.c_int(-1)
+    for d in (0, 1, 7, 63):
+        assert l.stgcn_launch_state(d, ctypes.byref(cus), ctypes.byref(opt)) == 0
+        assert cus.value == 0 and opt.value == 0            # nothing launched in this process: every slot untouched
+    assert l.stgcn_launch_state(64, ctypes.byref(cus), ctypes.byref(opt)) == 1
+    assert l.stgcn_launch_state(-1, None, None) == 1
+    # no launcher keeps a process-wide "already set" flag any more
+    src = os.path.join(ROOT, "st-gcn_amd", "csrc")
+    for f in os.listdir(src):
+        if f.endswith(".hip"):
+            txt = open(os.path.join(src, f)).read()
+            assert not re.search(r"static\s+bool\s+\w+(\[\d+\])?\s*=", txt), f
+            assert not re.search(r"\b256\s*/\s*\(?n", txt), f  # grids are sized from the device's CU count
+
+
 def test_no_cpu_fallback():
     from net.st_gcn import Model
     from net.utils.tgcn import ConvTemporalGraphical

@@ -23,6 +23,19 @@ def _free_port():
     return p
 
 
+class _AllImportances(torch.autograd.Function):
+    """One autograd node for every block's importance, as functional.EdgeImportanceFn is on the real model: all its
+    gradients appear together, after the first block's backward."""
+
+    @staticmethod
+    def forward(ctx, *imps):
+        return tuple(p.detach().sum() for p in imps)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        return tuple(torch.ones(3) * (0.0 if g is None else g) for g in grads)
+
+
 class TinyNet(torch.nn.Module):
     """fcn / st_gcn_networks / data_bn attribute names as in the real model so the ordering helper applies."""
 
@@ -36,8 +49,9 @@ class TinyNet(torch.nn.Module):
 
     def forward(self, x):
         h = self.data_bn(x)
-        for lin, imp in zip(self.st_gcn_networks, self.edge_importance):
-            h = torch.relu(lin(h)) * imp.sum()
+        sums = _AllImportances.apply(*self.edge_importance)
+        for lin, imp in zip(self.st_gcn_networks, sums):
+            h = torch.relu(lin(h)) * imp
         return self.fcn(h)
 
 
@@ -72,6 +86,12 @@ def _worker(rank, world, port, out):
     # hooks launched buckets in increasing (= reverse execution) order; the bucket holding only-unused params came from finish()
     assert launched_by_hooks == sorted(launched_by_hooks) and len(launched_by_hooks) >= 2
     assert sorted(bk.launched) == list(range(len(bk.buckets)))
+    # overlap: the first bucket is on its way before the first block's gradients (the end of backward) exist, and
+    # the importances -- one autograd node, ready last -- sit behind every block in the flat order
+    first_block = [i for i, p in enumerate(flat.params) if p is net.st_gcn_networks[0].weight][0]
+    assert bk.trace.index(("launch", 0)) < bk.trace.index(("grad", first_block))
+    ei_idx = [i for i, p in enumerate(flat.params) if any(p is q for q in net.edge_importance)]
+    assert min(ei_idx) > first_block and max(ei_idx) < [i for i, p in enumerate(flat.params) if p is net.data_bn.weight][0]
     avg = flat.grad * scale
     # reference: every rank recomputes both ranks' gradients serially
     ref = torch.zeros_like(flat.grad)

@@ -173,6 +173,41 @@ def dropout_keep_mask(numel, seed, p):
 
 
 # --------------------------------------------------------------------------
+# Storage rounding.  A reduced-precision implementation keeps activations, weights and the gradients that travel
+# between kernels in a 16-bit format and accumulates in float32.  Inside `with storage_rounding(torch.bfloat16):`
+# the functions below round to that format at exactly those places (weights as MFMA operands, the projected z and
+# A*importance as operands of the aggregation, every stored activation / gradient tensor) and evaluate everything
+# else in the inputs' dtype (float64 in the tests).  What is left between such an evaluation and the kernels is the
+# kernels' own arithmetic (float32 accumulation order); what separates it from the plain evaluation is the price of
+# the storage format.  Outside the context nothing is rounded.
+# --------------------------------------------------------------------------
+
+_RND = None
+
+
+class storage_rounding:
+    def __init__(self, dtype):
+        self.dtype = dtype
+
+    def __enter__(self):
+        global _RND
+        self.prev, _RND = _RND, self.dtype
+        return self
+
+    def __exit__(self, *exc):
+        global _RND
+        _RND = self.prev
+        return False
+
+
+def _q(t):
+    """t rounded to the storage format (and back to its own dtype); identity outside storage_rounding."""
+    if _RND is None or t is None:
+        return t
+    return t.to(_RND).to(t.dtype)
+
+
+# --------------------------------------------------------------------------
 # Graph convolution  (net/utils/tgcn.py:57-66), t_kernel_size == 1 form
 # --------------------------------------------------------------------------
 
@@ -185,6 +220,17 @@ def gcn_forward(x, A, W, b):
     K = A.shape[0]
     Cout = W.shape[0] // K
     Wk = W.reshape(K, Cout, -1)
+    if _RND is not None:
+        # projection first, as the kernels do: z_k = W_k x + b_k is rounded before it meets the (rounded) adjacency
+        Wq, Aq = _q(Wk), _q(A)
+        y = None
+        for k in range(K):
+            z = torch.matmul(Wq[k], x.permute(0, 2, 1, 3))                  # [B,T,Cout,V]
+            if b is not None:
+                z = z + b.reshape(K, Cout)[k][None, None, :, None]
+            t = torch.matmul(_q(z), Aq[k])                                   # [B,T,Cout,W]
+            y = t if y is None else y + t
+        return y.permute(0, 2, 1, 3).contiguous()
     y = None
     for k in range(K):
         xa = torch.matmul(x, A[k])                          # [B,Cin,T,W]
@@ -207,6 +253,21 @@ def gcn_backward(x, A, W, b, dy):
     dA = torch.zeros_like(A)
     db = None if b is None else torch.zeros(K, Cout, dtype=x.dtype, device=x.device)
     S = dy.sum(dim=(0, 2))                                  # [Cout, W]
+    if _RND is not None:
+        # the three kernels' operand roundings: dX projects dy through W_k^T first (rounded), then aggregates with
+        # A_k^T; dW forms dz_k = dy A_k^T (rounded) and contracts it with x; dA contracts the rounded z_k with dy
+        Wq, Aq = _q(Wk), _q(A)
+        for k in range(K):
+            u = torch.matmul(Wq[k].t(), dy.permute(0, 2, 1, 3))            # [B,T,Cin,W]
+            dx += torch.matmul(_q(u), Aq[k].t()).permute(0, 2, 1, 3)
+            dz = _q(torch.matmul(dy, Aq[k].t()))                             # [B,Cout,T,V]
+            dW[k] = torch.tensordot(dz, x, dims=([0, 2, 3], [0, 2, 3]))
+            z = torch.matmul(Wq[k], x.permute(0, 2, 1, 3)).permute(0, 2, 1, 3)
+            if b is not None:
+                z = z + b.reshape(K, Cout)[k][None, :, None, None]
+                db[k] = dz.sum(dim=(0, 2, 3))
+            dA[k] = torch.tensordot(_q(z), dy, dims=([0, 1, 2], [0, 1, 2]))
+        return dx, dW.reshape(W.shape), (None if b is None else db.reshape(-1)), dA
     for k in range(K):
         dz = torch.matmul(dy, A[k].t())                     # [B,Cout,T,V]  grad of projected z_k
         dx += torch.matmul(Wk[k].t(), dz.permute(0, 2, 1, 3)).permute(0, 2, 1, 3)
@@ -351,14 +412,14 @@ def block_forward(x, A, p, bufs, stride, residual_kind, training, keep=None, kee
     """
     K = A.shape[0]
     Wg = p["gcn.conv.weight"].reshape(p["gcn.conv.weight"].shape[0], -1)
-    y = gcn_forward(x, A, Wg, p["gcn.conv.bias"])
+    y = _q(gcn_forward(x, A, Wg, p["gcn.conv.bias"]))        # stored; BatchNorm statistics are those of the stored values
     nb = {}
     h1, c1, (nb["tcn.0.running_mean"], nb["tcn.0.running_var"]) = bn_forward(
         y, p["tcn.0.weight"], p["tcn.0.bias"], bufs["tcn.0.running_mean"], bufs["tcn.0.running_var"], training)
     hmask = (h1 > 0) if h_mask is None else h_mask
-    h = h1 * hmask.to(h1.dtype)
+    h = _q(h1 * hmask.to(h1.dtype))
     Wt = p["tcn.2.weight"][..., 0]                           # [C,C,9]
-    o = tconv_forward(h, Wt, p["tcn.2.bias"], stride)
+    o = _q(tconv_forward(h, _q(Wt), p["tcn.2.bias"], stride))
     q, c2, (nb["tcn.3.running_mean"], nb["tcn.3.running_var"]) = bn_forward(
         o, p["tcn.3.weight"], p["tcn.3.bias"], bufs["tcn.3.running_mean"], bufs["tcn.3.running_var"], training)
     if keep is not None:
@@ -368,7 +429,7 @@ def block_forward(x, A, p, bufs, stride, residual_kind, training, keep=None, kee
         s = q + x
     elif residual_kind == "conv":
         Wr = p["residual.0.weight"][..., 0]                  # [Cout,Cin,1]
-        r = tconv_forward(x, Wr, p["residual.0.bias"], stride, pad=0)
+        r = _q(tconv_forward(x, _q(Wr), p["residual.0.bias"], stride, pad=0))
         rb, cr, (nb["residual.1.running_mean"], nb["residual.1.running_var"]) = bn_forward(
             r, p["residual.1.weight"], p["residual.1.bias"],
             bufs["residual.1.running_mean"], bufs["residual.1.running_var"], training)
@@ -377,8 +438,8 @@ def block_forward(x, A, p, bufs, stride, residual_kind, training, keep=None, kee
     else:
         s = q
     omask = (s > 0) if out_mask is None else out_mask
-    out = s * omask.to(s.dtype)
-    cache["out"], cache["omask"] = out, omask
+    out = _q(s * omask.to(s.dtype))
+    cache["out"], cache["omask"], cache["s"] = out, omask, s
     return out, cache, nb
 
 
@@ -388,25 +449,28 @@ def block_backward(dout, p, cache, stride, residual_kind, training):
     ds = dout * cache["omask"].to(dout.dtype)
     dq = ds if cache["keep"] is None else ds * cache["keep"] * cache["keep_scale"]
     do, g["tcn.3.weight"], g["tcn.3.bias"] = bn_backward(cache["o"], p["tcn.3.weight"], cache["c2"], dq, training)
+    do = _q(do)
     h = cache["h"]
     Wt = p["tcn.2.weight"][..., 0]
-    dh, dWt, g["tcn.2.bias"] = tconv_backward(h, Wt, do, stride)
+    dh, dWt, g["tcn.2.bias"] = tconv_backward(h, _q(Wt), do, stride)
     g["tcn.2.weight"] = dWt[..., None]
-    dh1 = dh * cache["hmask"].to(dh.dtype)
+    dh1 = _q(dh * cache["hmask"].to(dh.dtype))
     dy, g["tcn.0.weight"], g["tcn.0.bias"] = bn_backward(cache["y"], p["tcn.0.weight"], cache["c1"], dh1, training)
+    dy = _q(dy)
     Wg = p["gcn.conv.weight"].reshape(p["gcn.conv.weight"].shape[0], -1)
     dx, dWg, g["gcn.conv.bias"], dA = gcn_backward(cache["x"], cache["A"], Wg, p["gcn.conv.bias"], dy)
     g["gcn.conv.weight"] = dWg.reshape(p["gcn.conv.weight"].shape)
     if residual_kind == "identity":
-        dx = dx + ds
+        dx = dx + _q(ds)
     elif residual_kind == "conv":
         dr, g["residual.1.weight"], g["residual.1.bias"] = bn_backward(
             cache["r"], p["residual.1.weight"], cache["cr"], ds, training)
+        dr = _q(dr)
         Wr = p["residual.0.weight"][..., 0]
-        dxr, dWr, g["residual.0.bias"] = tconv_backward(cache["x"], Wr, dr, stride, pad=0)
+        dxr, dWr, g["residual.0.bias"] = tconv_backward(cache["x"], _q(Wr), dr, stride, pad=0)
         g["residual.0.weight"] = dWr[..., None]
-        dx = dx + dxr
-    return dx, dA, g
+        dx = dx + _q(dxr)
+    return _q(dx), dA, g
 
 
 # --------------------------------------------------------------------------
@@ -508,7 +572,7 @@ def model_forward(sd, x, training, dropout=0.0, seeds=None, return_feature=False
     xp = x.permute(0, 4, 3, 1, 2).reshape(N * M, V * C, T)
     xb, cd, (newb["data_bn.running_mean"], newb["data_bn.running_var"]) = bn_forward(
         xp, sd["data_bn.weight"], sd["data_bn.bias"], sd["data_bn.running_mean"], sd["data_bn.running_var"], training)
-    h = xb.reshape(N, M, V, C, T).permute(0, 1, 3, 4, 2).reshape(N * M, C, T, V)
+    h = _q(xb.reshape(N, M, V, C, T).permute(0, 1, 3, 4, 2).reshape(N * M, C, T, V))
     caches = []
     for i, (cin, cout, stride, res) in enumerate(BLOCK_SPECS):
         cin = C if cin is None else cin

@@ -14,6 +14,7 @@ from . import ops as P
 # Test hook: when set to a list, every StGcnBlockFn.backward appends the two ReLU decisions it used
 # (inner ReLU after BN1, final ReLU) so a checker can evaluate its reference with the same decisions.
 CAPTURE = None
+CAPTURE_TENSORS = False
 
 
 def _act_dtype(dtype):
@@ -182,9 +183,13 @@ class StGcnBlockFn(torch.autograd.Function):
         gh = P.conv_rows(dO, packs[1][1], Cout, T, epilogue=L.EPI_RELU_BWD, aux=y, ep=(bn1.scale, bn1.shift, bn1.mean, bn1.rstd),
                          stats=stats1, ntaps=kt, stride=stride, pad=pad, transposed=True)
         if CAPTURE is not None:
-            pre = y.float() * bn1.scale[None, :, None, None] + bn1.shift[None, :, None, None]
-            near = pre.abs() < 1e-4          # decided by the kernel's own fma there: read it off its output
-            CAPTURE.append(dict(h_mask=torch.where(near, gh != 0, pre > 0), out_mask=(out > 0)))
+            # the kernels decide by the sign of fmaf(y, scale, shift): y * scale is exact in float64 (at most 48
+            # significant bits) and a float64 sum keeps the exact sum's sign, so this is their decision bit for bit
+            pre = y.double() * bn1.scale.double()[None, :, None, None] + bn1.shift.double()[None, :, None, None]
+            CAPTURE.append(dict(h_mask=pre > 0, out_mask=(out > 0)))
+            if CAPTURE_TENSORS:                  # diagnostics (tools/grad_budget.py): what each kernel read and wrote
+                CAPTURE[-1].update(x=x, y=y, o=o, r=r_, dout=dout, dpool=dpool, dO=dO, dR=dR, g=g, gh=gh.clone(),
+                                   bn=(bn1, bn2, bnr), relu_mask=ctx.relu_mask)
         dy, dg1, db1 = P.bn_bwd_apply(gh, y, f32(g1), bn1, stats1, training, out=gh, want_grads=True)
 
         add = g
@@ -202,6 +207,8 @@ class StGcnBlockFn(torch.autograd.Function):
         dA = None
         if ctx.needs_input_grad[1]:
             dA = P.gcn_agrad(x, packs[0][0], f32(bg), dy)
+        if CAPTURE is not None and CAPTURE_TENSORS:
+            CAPTURE[-1].update(dy=dy, dx=dx, dA=dA, add=add)
         return (dx, dA, dWg, dbg, dg1, db1, dWt, dbt, dg2, db2, dWr, dbr_f, dgr, dbetar,
                 None, None, None, None, None, None, None, None)
 

@@ -43,6 +43,32 @@ def cpu64(t):
     return t.detach().to("cpu", torch.float64)
 
 
+# A reduced-precision evaluation decides a ReLU differently from float64 only where the float64 pre-activation is
+# within its own error of zero: bound on |pre-activation| / rms(pre-activation tensor) over such elements.
+FLIP_BOUND = {torch.float32: 1e-4, torch.bfloat16: 0.5}
+
+
+def _relu_flips(plain_cache, masks):
+    """(count, largest |float64 pre-activation| / rms) over the elements whose ReLU decision in `masks`
+    ({block: (inner, final)}, the kernels') differs from the plain float64 evaluation's."""
+    n, worst = 0, 0.0
+    for i, bc in enumerate(plain_cache["blocks"]):
+        for mine, theirs, pre in ((masks[i][0], bc["hmask"], bc["h1"]), (masks[i][1], bc["omask"], bc["s"])):
+            flip = mine.bool() != theirs.bool()
+            k = int(flip.sum())
+            if k:
+                n += k
+                worst = max(worst, float(pre[flip].abs().max() / pre.pow(2).mean().sqrt()))
+    return n, worst
+
+
+def _sample(g):
+    """The elements of a gradient tensor the model fixtures keep (tests/golden/make_golden.py: every
+    max(1, numel // 257)-th)."""
+    flat = g.reshape(-1)
+    return flat[:: max(1, flat.numel() // 257)]
+
+
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
 @pytest.mark.parametrize("ci", range(len(C.GCN_CASES)), ids=[c[0] for c in C.GCN_CASES])
 def test_conv_temporal_graphical(net, golden, ci, dtype):
@@ -188,37 +214,58 @@ def test_model(net, golden, ci, dtype):
                 assert rel(cpu64(rsd[key.split("buf:")[1]]), G[key]) < tol, key
         assert int(rsd["data_bn.num_batches_tracked"]) == 1
         sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+        skip = lambda k: k.endswith("tcn.2.bias") or k.endswith("residual.0.bias")      # zero up to rounding noise
+        got = {k: cpu64(prm.grad) for k, prm in m.named_parameters() if not skip(k)}
+
+        # 1. The kernels' ReLU decisions against the plain float64 evaluation: they may differ only where the float64
+        #    pre-activation is within the storage format's rounding error of zero.
+        nflip, ratio = _relu_flips(O.model_forward(sd64, x, True)[1], masks)
+        print("ReLU decisions differing from the float64 evaluation: %d, largest |pre-activation| / rms among them: %.2e" % (nflip, ratio))
+        assert ratio < FLIP_BOUND[dtype], (nflip, ratio)
+
+        # 2. Directly against the reference's own gradients (its ReLU decisions, its logits): every 257th element of
+        #    every tensor is in the fixtures.  One differing decision switches one element's gradient path on or off,
+        #    which moves the small tensors of these two-clip cases (edge_importance: 73 sums) by up to 1e-2; with no
+        #    differing decision (it happens: the count varies with the order of the BatchNorm atomics) the match is 1e-4.
+        dd = sorted(((rel_l2(_sample(got[k]), G[name + "/gsample:" + k]), k) for k in got), reverse=True)
+        direct = dd[0][0]
+        print("worst gradient rel-L2 deviations from the reference's golden samples:", dd[:4])
+        #    A bf16 evaluation decides about 0.5 % of the ReLUs differently (pre-activations within its error of zero, bound
+        #    asserted above), so its gradients are those of a slightly different piecewise-linear function: on these
+        #    ill-conditioned cases (each gradient is what is left of sums that cancel 10-70x) they sit 30-60 % from the
+        #    float64 ones.  tests/test_oracle_golden.py::test_one_relu_decision_moves_gradients shows the same
+        #    sensitivity inside float64 alone.  bf16 is therefore bounded against the decision-consistent oracle below.
+        assert direct < (1e-4 + 1.5e-2 * nflip if dtype == torch.float32 else 1.0), (direct, nflip)
+
+        # 3. Against the oracle evaluated with the kernels' decisions and the GPU's d loss / d logits (the softmax turns
+        #    an absolute logit error e into a relative probability error e, which says nothing about the backward kernels).
         lo, cache, _ = O.model_forward(sd64, x, True, masks=masks)
-        # back-propagate the SAME upstream gradient the kernels received (d loss / d logits at the GPU's logits):
-        # the softmax turns an absolute logit error e into a relative probability error e, which would otherwise
-        # dominate every bf16 gradient without saying anything about the backward kernels
         _, dlog = O.cross_entropy(cpu64(logits), labels)
         ref_g = O.model_backward(sd64, cache, dlog, True)
-        worst = ("", 0.0)
-        for k, prm in m.named_parameters():
-            if k.endswith("tcn.2.bias") or k.endswith("residual.0.bias"):
-                continue                                   # zero up to rounding noise
-            e = rel_l2(cpu64(prm.grad), ref_g[k])
-            if e > worst[1]:
-                worst = (k, e)
+        errs = {k: rel_l2(got[k], ref_g[k]) for k in got}
+        worst = max(errs.items(), key=lambda kv: kv[1])
         print("worst gradient rel-L2 error vs mask-consistent oracle:", worst)
-        # float32: 1e-4.  bfloat16: activations, weights and A are rounded to 8 significant bits at every kernel
-        # boundary; gradients that are small differences of large sums (edge_importance: sum_kvw A*dA vanishes
-        # identically behind a train-mode BatchNorm; BN weights of the last block) reach 3-5 % relative L2, every
-        # other tensor stays under 2e-2 -- bound the worst at 6e-2 and the median at 2e-2.
-        errs = sorted(rel_l2(cpu64(prm.grad), ref_g[k]) for k, prm in m.named_parameters()
-                      if not (k.endswith("tcn.2.bias") or k.endswith("residual.0.bias")))
-        assert worst[1] < (tol if dtype == torch.float32 else 6e-2), worst
-        assert errs[len(errs) // 2] < tol, errs[len(errs) // 2]
-        # against the golden float64 gradients of the reference (its own ReLU decisions): loose bound only
-        loose = 0.0
-        for k, prm in m.named_parameters():
-            if k.endswith("tcn.2.bias") or k.endswith("residual.0.bias"):
-                continue
-            ref_norm = float(G[name + "/gnorm:" + k])
-            loose = max(loose, abs(cpu64(prm.grad).norm().item() - ref_norm) / (ref_norm + 1e-30))
-        print("worst gradient-norm deviation vs golden:", loose)
-        assert loose < (0.05 if dtype == torch.float32 else 0.5)
+        if dtype == torch.float32:
+            assert worst[1] < tol, worst
+        else:
+            # bfloat16.  Activations, weights and the gradients between kernels are rounded to 8 significant bits at
+            # every kernel boundary, ~70 roundings deep by the last block; an exact evaluation of the reference's
+            # formulas with only those roundings (oracle.storage_rounding) deviates from float64 by 2-4 % on the
+            # tensors of the last blocks and on edge_importance.  That deviation is the format's, not the kernels':
+            # each tensor must stay within 2e-2, or within 1.6x of what the format itself costs that tensor (the two
+            # are different realisations of the same rounding noise), and the worst and the median over all tensors
+            # within 1.2x of the format's worst and median.
+            with O.storage_rounding(torch.bfloat16):
+                _, cache_q, _ = O.model_forward(sd64, x, True, masks=masks)
+                fmt_g = O.model_backward(sd64, cache_q, dlog, True)
+            fmt = {k: rel_l2(fmt_g[k], ref_g[k]) for k in got}
+            print("bf16-storage oracle vs float64 oracle: worst %.2e, median %.2e; kernels: worst %.2e, median %.2e"
+                  % (max(fmt.values()), sorted(fmt.values())[len(fmt) // 2], worst[1], sorted(errs.values())[len(errs) // 2]))
+            for k in got:
+                assert errs[k] < max(tol, 1.6 * fmt[k]), (k, errs[k], fmt[k])
+            med = lambda d: sorted(d.values())[len(d) // 2]
+            assert worst[1] < min(6e-2, 1.2 * max(fmt.values())), (worst, max(fmt.values()))
+            assert med(errs) < max(tol, 1.2 * med(fmt)), (med(errs), med(fmt))
     if name.endswith("small_eval"):
         out, feat = m.extract_feature(x.float().to(DEV))
         assert rel(cpu64(out), G[name + "/feat_output"]) < tol

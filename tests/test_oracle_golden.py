@@ -144,3 +144,30 @@ def test_dropout_mask_rate():
     m2 = O.dropout_keep_mask(200000, 1235, 0.5)
     assert (m != m2).mean() > 0.4
     assert O.dropout_keep_mask(100, 1, 0.0).min() == 1.0
+
+
+def test_one_relu_decision_moves_gradients():
+    """Conditioning of the whole-model gradient cases: in float64 alone, switching the ONE ReLU decision whose
+    pre-activation is closest to zero (|pre| < 1e-4 rms: the forward does not notice) moves some parameter-gradient
+    tensor by more than 1e-3 relative L2.  The gradients of these two-clip cases are small remainders of cancelling
+    sums, which is why the GPU tests evaluate the oracle with the kernels' own decisions and bound, separately, how
+    far from zero a differently decided pre-activation may be."""
+    name, lay, ncls, N, T, M, training = C.MODEL_CASES[0]
+    g = O.build_graph(lay, "spatial")
+    sd = O.det_state(3, ncls, g["A"], True)
+    x, labels = C.model_inputs(0)
+    lo, cache, _ = O.model_forward(sd, x, True)
+    _, dlog = O.cross_entropy(lo, labels)
+    g0 = O.model_backward(sd, cache, dlog, True)
+    masks = {i: (bc["hmask"].clone(), bc["omask"].clone()) for i, bc in enumerate(cache["blocks"])}
+    pre = cache["blocks"][2]["h1"]
+    idx = pre.abs().reshape(-1).argmin()
+    assert float(pre.reshape(-1)[idx].abs() / pre.pow(2).mean().sqrt()) < 1e-4
+    flat = masks[2][0].reshape(-1)
+    flat[idx] = ~flat[idx]
+    lo1, c1, _ = O.model_forward(sd, x, True, masks=masks)
+    g1 = O.model_backward(sd, c1, dlog, True)
+    assert float((lo1 - lo).norm() / lo.norm()) < 1e-6
+    moved = max(float((g1[k] - g0[k]).norm() / g0[k].norm()) for k in g0
+                if not (k.endswith("tcn.2.bias") or k.endswith("residual.0.bias")))
+    assert moved > 1e-3, moved

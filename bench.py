@@ -80,7 +80,31 @@ def recorded_traffic(key):
 
 
 def cpu_baseline(n_clips, steps, threads):
-    """The CPU oracle's training step (float32 torch CPU ops), bounded sample of the same workload."""
+    """The same training step on stock PyTorch CPU operators -- F.conv2d, einsum, F.batch_norm, F.dropout, autograd,
+    optim.SGD: the operators the reference's CPU path runs (oracle/torch_step.py, pinned to the golden vectors) --
+    on a bounded sample of the workload."""
+    from oracle import stgcn_oracle as O
+    from oracle import torch_step as TS
+    torch.set_num_threads(threads)
+    g = O.build_graph("ntu-rgb+d", "spatial")
+    st = TS.Stepper(O.det_state(3, 60, g["A"], True, dtype=torch.float32), lr=0.1, dropout=0.5)
+    gen = torch.Generator().manual_seed(0)
+    x = torch.randn(n_clips, 3, 300, 25, 2, generator=gen)
+    labels = torch.randint(0, 60, (n_clips,), generator=gen)
+    times = []
+    for it in range(steps + 1):
+        t0 = time.perf_counter()
+        st.step(x, labels)
+        if it > 0:                                              # first iteration warms the allocator up
+            times.append(time.perf_counter() - t0)
+    t = sum(times) / len(times)
+    return {"value": round(n_clips / t, 3), "unit": "clips/s", "cores": threads, "kind": "port",
+            "sample": "%d timed steps (1 warm-up) of the stock-PyTorch-operator restatement at N=%d clips, T=300, V=25, M=2, float32, "
+                      "dropout 0.5, SGD-nesterov" % (steps, n_clips)}
+
+
+def cpu_baseline_oracle(n_clips, steps, threads):
+    """The explicit-formula CPU oracle's training step (float32 torch CPU tensor ops, tap loops), bounded sample."""
     from oracle import stgcn_oracle as O
     torch.set_num_threads(threads)
     g = O.build_graph("ntu-rgb+d", "spatial")
@@ -101,11 +125,12 @@ def cpu_baseline(n_clips, steps, threads):
         O.sgd_nesterov_step(prm, grads, moms, 0.1)
         sd.update(prm)
         sd.update(newb)
-        if it > 0:                                              # first iteration warms the allocator up
+        if it > 0:
             times.append(time.perf_counter() - t0)
     t = sum(times) / len(times)
     return {"value": round(n_clips / t, 3), "unit": "clips/s", "cores": threads, "kind": "port",
-            "sample": "%d timed oracle steps (1 warm-up) at N=%d clips, T=300, V=25, M=2, float32, dropout 0.5, SGD-nesterov" % (steps, n_clips)}
+            "sample": "%d timed steps (1 warm-up) of the explicit-formula oracle at N=%d clips, T=300, V=25, M=2, float32, dropout 0.5, "
+                      "SGD-nesterov" % (steps, n_clips)}
 
 
 def main():
@@ -119,7 +144,9 @@ def main():
                     help="strong scaling: --batch is the global batch (the reference's 64), split evenly over the GPUs")
     ap.add_argument("--frames", type=int, default=300)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-clips", type=int, default=2)
+    ap.add_argument("--cpu-clips", type=int, default=8)
+    ap.add_argument("--single-dtype", action="store_true", help="time --dtype only (default: the other precision is timed too and reported as a nested record)")
+    ap.add_argument("--no-graph", action="store_true", help="issue every step launch by launch instead of replaying the captured HIP graph")
     ap.add_argument("--kernel-table", action="store_true", help="print the per-kernel time table to stderr")
     args = ap.parse_args()
 
@@ -150,9 +177,19 @@ def main():
     from stgcn_rt import ops as P
     from stgcn_rt.ddp import Trainer
 
-    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
-    torch.manual_seed(1234)
-    model = Model(3, 60, dict(layout="ntu-rgb+d", strategy="spatial"), True, dropout=0.5, compute_dtype=dtype).to(dev)
+    if args.strong:
+        if args.batch % world != 0:
+            raise SystemExit("--strong: the global batch %d does not split over %d GPUs" % (args.batch, world))
+        args.batch //= world                                    # clips per GPU from here on
+    gen = torch.Generator().manual_seed(rank)                   # synthetic data: x ~ N(0,1), labels uniform
+    x = torch.randn(args.batch, 3, args.frames, 25, 2, generator=gen).to(dev)
+    labels = torch.randint(0, 60, (args.batch,), generator=gen).to(dev)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
 
     def weights_init(m):                                        # processor/recognition.py:21-33
         cn = m.__class__.__name__
@@ -163,88 +200,107 @@ def main():
         elif cn.find("BatchNorm") != -1:
             m.weight.data.normal_(1.0, 0.02)
             m.bias.data.fill_(0)
-    model.apply(weights_init)
-    model.train()
-    trainer = Trainer(model, lr=0.1, momentum=0.9, weight_decay=1e-4, nesterov=True)
-    trainer.broadcast_from_rank0()
 
-    gen = torch.Generator().manual_seed(rank)                   # synthetic data: x ~ N(0,1), labels uniform
-    if args.strong:
-        if args.batch % world != 0:
-            raise SystemExit("--strong: the global batch %d does not split over %d GPUs" % (args.batch, world))
-        args.batch //= world                                    # clips per GPU from here on
-    x = torch.randn(args.batch, 3, args.frames, 25, 2, generator=gen).to(dev)
-    labels = torch.randint(0, 60, (args.batch,), generator=gen).to(dev)
+    def run(dtype_name, steps, warmup):
+        """W warm-up steps, then K timed steps of the training iteration in `dtype_name`; -> record (rank 0: dict)."""
+        dtype = torch.bfloat16 if dtype_name == "bf16" else torch.float32
+        torch.manual_seed(1234)
+        model = Model(3, 60, dict(layout="ntu-rgb+d", strategy="spatial"), True, dropout=0.5, compute_dtype=dtype).to(dev)
+        model.apply(weights_init)
+        model.train()
+        trainer = Trainer(model, lr=0.1, momentum=0.9, weight_decay=1e-4, nesterov=True, graph=not args.no_graph)
+        trainer.broadcast_from_rank0()
 
-    def barrier():
-        torch.cuda.synchronize()
+        # warm-up; the last warm-up step also records every kernel to find the one that dominates
+        for i in range(warmup):
+            if i == warmup - 1:
+                P.TIMING, P.TIMING_NAMES = {}, None
+                trainer.step(x, labels, eager=True)
+            else:
+                trainer.step(x, labels)
+        table = P.timing_summary() if P.TIMING is not None else {}
+        P.TIMING = None
+        by_name = {}
+        for k, (n, mean, tot) in table.items():
+            by_name[k[0]] = by_name.get(k[0], 0.0) + tot
+        if args.kernel_table and rank == 0:
+            tot_all = sum(by_name.values())
+            print("%s: per-kernel time of one step (ms), total %.2f" % (dtype_name, tot_all), file=sys.stderr)
+            for k, (n, mean, tot) in sorted(table.items(), key=lambda kv: -kv[1][2]):
+                fl, by, bound = kernel_work(k)
+                print("  %7.3f ms x%-2d  %6.1f TFLOP/s %7.1f GB/s  %s" % (mean, n, fl / mean / 1e9, by / mean / 1e6, k), file=sys.stderr)
+        # the kernel instance that takes the most time of a step; it is priced from launches bracketed by events on
+        # the launch stream during the timed region (eager steps interleaved with the timed ones would distort the
+        # step time, so with graph replay the instance is timed in extra eager steps right after the timed region)
+        dom_key = max(table, key=lambda k: table[k][2]) if table else None
+
+        graphed = trainer.prepare_graph(x, labels)               # captured here, outside the timed region
+        if dom_key is not None and not graphed:
+            P.TIMING, P.TIMING_NAMES = {}, {dom_key[0]}
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = trainer.step(x, labels)
+        host_issue = time.perf_counter() - t0                    # the host's share: launching, autograd bookkeeping
+        barrier()
+        elapsed = time.perf_counter() - t0
         if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    # warm-up; the last warm-up step also records every kernel to find the one that dominates
-    for i in range(args.warmup):
-        if i == args.warmup - 1:
-            P.TIMING, P.TIMING_NAMES = {}, None
-        trainer.step(x, labels)
-    table = P.timing_summary() if P.TIMING is not None else {}
-    P.TIMING = None
-    by_name = {}
-    for k, (n, mean, tot) in table.items():
-        by_name[k[0]] = by_name.get(k[0], 0.0) + tot
-    dom_name = max(by_name, key=by_name.get) if by_name else None
-    if args.kernel_table and rank == 0:
-        tot_all = sum(by_name.values())
-        print("per-kernel time of one step (ms), total %.2f" % tot_all, file=sys.stderr)
-        for k, (n, mean, tot) in sorted(table.items(), key=lambda kv: -kv[1][2]):
-            fl, by, bound = kernel_work(k)
-            print("  %7.3f ms x%-2d  %6.1f TFLOP/s %7.1f GB/s  %s" % (mean, n, fl / mean / 1e9, by / mean / 1e6, k), file=sys.stderr)
-
-    # timed region: only the dominant kernel is bracketed by events
-    if dom_name is not None:
-        P.TIMING, P.TIMING_NAMES = {}, {dom_name}
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = trainer.step(x, labels)
-    host_issue = time.perf_counter() - t0                        # the host's share: launching, autograd bookkeeping
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = t.item()
-    timed = P.timing_summary() if P.TIMING is not None else {}
-    P.TIMING = None
-
-    if rank == 0:
-        clips = args.batch * world * args.steps
+            t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = t.item()
+        if dom_key is not None and graphed:
+            P.TIMING, P.TIMING_NAMES = {}, {dom_key[0]}
+            for _ in range(min(steps, 5)):
+                trainer.step(x, labels, eager=True)
+        timed = P.timing_summary() if P.TIMING is not None else {}
+        P.TIMING = None
+        final_loss = float(loss.item())
+        del trainer, model
+        torch.cuda.empty_cache()
+        if rank != 0:
+            return None
         roof = None
         if timed:
-            # dominant instance = the key with the largest total time
             key, (n, mean, tot) = max(timed.items(), key=lambda kv: kv[1][2])
             fl, by, bound = kernel_work(key)
             if bound == "mfma":
-                ach, peak, unit = fl / mean / 1e9, PEAK[args.dtype], "TFLOP/s"
+                ach, peak, unit = fl / mean / 1e9, PEAK[dtype_name], "TFLOP/s"
             else:
                 ach, peak, unit = by / mean / 1e6, HBM_PEAK, "GB/s"
             roof = {"bound": bound, "achieved": round(ach, 2), "peak": peak, "unit": unit, "frac": round(ach / peak, 4),
                     "traffic": recorded_traffic(key), "kernel": key[0].replace("stgcn_", ""), "launch": list(map(str, key[1:])),
                     "avg_launch_ms": round(mean, 4), "launches_timed": n,
-                    "share_of_step": round(sum(v[2] for v in timed.values()) / (elapsed * 1e3), 3)}
-        cpu = None
+                    "timed_in": "eager steps after the timed region" if graphed else "the timed region"}
+        return {"value": round(args.batch * world * steps / elapsed, 2), "ms_per_step": round(elapsed / steps * 1e3, 3),
+                "host_issue_ms_per_step": round(host_issue / steps * 1e3, 3), "steps": steps, "warmup": warmup,
+                "hip_graph": bool(graphed), "final_loss": round(final_loss, 4), "roofline": roof}
+
+    head = run(args.dtype, args.steps, args.warmup)
+    other = None
+    if not args.single_dtype:
+        # the reference's own arithmetic (float32, processor/recognition.py:87-91) next to the bf16 headline -- or the
+        # other way round --, same workload, same timed region, same invocation
+        other_name = "fp32" if args.dtype == "bf16" else "bf16"
+        other = run(other_name, args.steps, args.warmup)
+
+    if rank == 0:
+        cpu = cpu_o = None
         if world == 1 and not args.no_cpu_baseline:
-            cpu = cpu_baseline(args.cpu_clips, 2, min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16"))))
+            threads = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")))
+            cpu = cpu_baseline(args.cpu_clips, 3, threads)
+            cpu_o = cpu_baseline_oracle(2, 1, threads)
         line = {
-            "metric": "train clips/sec, ST-GCN NTU-60 (T=300,V=25,M=2)", "value": round(clips / elapsed, 2), "unit": "clips/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
-            "host_issue_ms_per_step": round(host_issue / args.steps * 1e3, 3),
+            "metric": "train clips/sec, ST-GCN NTU-60 (T=300,V=25,M=2)", "value": head["value"], "unit": "clips/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["ms_per_step"],
+            "host_issue_ms_per_step": head["host_issue_ms_per_step"], "hip_graph": head["hip_graph"],
             "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "NTU-RGB+D xsub training step (forward + cross-entropy + backward + SGD-nesterov), "
                                    "%d clips per GPU, T=%d, V=25, M=2, 60 classes, spatial K=3, dropout 0.5" % (args.batch, args.frames),
-                       "global_batch": args.batch * world, "parallelism": "dp%d" % world, "final_loss": round(float(loss.item()), 4)},
-            "roofline": roof, "cpu_baseline": cpu,
+                       "global_batch": args.batch * world, "parallelism": "dp%d" % world, "final_loss": head["final_loss"]},
+            "roofline": head["roofline"], "cpu_baseline": cpu, "cpu_baseline_oracle": cpu_o,
         }
+        if other is not None:
+            line[other_name] = other
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

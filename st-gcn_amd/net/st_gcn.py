@@ -43,6 +43,9 @@ class Model(nn.Module):
                 (64, 64, 1, kwargs), (64, 128, 2, kwargs), (128, 128, 1, kwargs), (128, 128, 1, kwargs),
                 (128, 256, 2, kwargs), (256, 256, 1, kwargs), (256, 256, 1, kwargs)]
         self.st_gcn_networks = nn.ModuleList(st_gcn(ci, co, kernel_size, s, **kw) for ci, co, s, kw in plan)
+        for i, blk in enumerate(self.st_gcn_networks):
+            blk.block_index = i                         # enters the block's dropout seed
+        self._drop_step = None                          # device-side count of training forwards (dropout stream position)
 
         if edge_importance_weighting:
             self.edge_importance = nn.ParameterList(
@@ -86,6 +89,15 @@ class Model(nn.Module):
                            P.pad_to(C, P.kstep(dtype)))
         packs = self._packed_weights(dtype, h.device)
         counters = [bn.num_batches_tracked] if self.training else None
+        step = None
+        if self.training:
+            # The dropout masks of a step are drawn from (per-block seed, step count); the count lives on the device
+            # and advances with the BatchNorm counters below, so a step replayed from a captured HIP graph draws
+            # fresh masks although every launch argument is frozen in the graph.
+            if self._drop_step is None or self._drop_step.device != h.device:
+                self._drop_step = torch.zeros((), dtype=torch.int64, device=h.device)
+            step = self._drop_step
+            counters.append(step)
         last = len(self.st_gcn_networks) - 1
         if isinstance(self.edge_importance, nn.ParameterList):
             a_eff = EdgeImportanceFn.apply(self.A, *self.edge_importance)       # A * importance, all blocks at once
@@ -94,7 +106,7 @@ class Model(nn.Module):
         for i, gcn in enumerate(self.st_gcn_networks):
             # global average pool over (T, V) fused into the last block (st_gcn.py:85 of the reference)
             want_pool = pool_last and i == last
-            h, pooled = gcn._run(h, a_eff[i], want_pool, packs=packs[i], counters=counters)
+            h, pooled = gcn._run(h, a_eff[i], want_pool, packs=packs[i], counters=counters, drop_step=step)
             if want_pool:
                 h = pooled
         if counters:
@@ -150,11 +162,15 @@ class st_gcn(nn.Module):
             )
         self.relu = nn.ReLU(inplace=True)
         self.compute_dtype = None
-        self._calls = 0
+        self.block_index = 0
+        self._drop_step = None
 
     def _seed(self):
-        self._calls += 1
-        return (torch.initial_seed() * 0x9E3779B1 + self._calls * 0x85EBCA6B + id(self) % 65521) & 0xFFFFFFFF
+        """Dropout seed of this block: a function of torch's seed, the block's position in the model and the
+        process's rank (data-parallel replicas draw different masks, as nn.DataParallel replicas do) -- nothing that
+        changes from run to run.  The position inside the stream of masks is the device-side step count."""
+        rank = torch.distributed.get_rank() if torch.distributed.is_available() and torch.distributed.is_initialized() else 0
+        return (torch.initial_seed() * 0x9E3779B1 + (self.block_index + 1) * 0x632BE5AB + rank * 0xC2B2AE35) & 0xFFFFFFFF
 
     def forward(self, x, A):
         return self._run(x, A, False)[0], A
@@ -163,9 +179,10 @@ class st_gcn(nn.Module):
         """-> (y, mean of y over (T, V) as float32 [B, C])."""
         return self._run(x, A, True)
 
-    def _run(self, x, A, want_pool, packs=None, counters=None):
+    def _run(self, x, A, want_pool, packs=None, counters=None, drop_step=None):
         """packs: this block's pre-packed weights (Model packs all blocks with one launch); counters: a list that
-        collects the num_batches_tracked buffers for a batched increment instead of bumping them here."""
+        collects the num_batches_tracked buffers for a batched increment instead of bumping them here; drop_step: the
+        model's device-side step count (a block used on its own keeps one itself)."""
         assert A.size(0) == self.gcn.kernel_size
         dtype = self.compute_dtype or (x.dtype if x.dtype in (torch.float32, torch.bfloat16) else torch.float32)
         cin = self.in_channels
@@ -181,7 +198,12 @@ class st_gcn(nn.Module):
             rbufs = (rb.running_mean, rb.running_var)
         else:
             rargs, rbufs = (None, None, None, None), (None, None)
-        cfg = (self.stride, self.residual_kind, self.training, float(drop.p), self._seed(), cin, want_pool)
+        own_step = None
+        if self.training and drop.p > 0 and drop_step is None:
+            if self._drop_step is None or self._drop_step.device != x.device:
+                self._drop_step = torch.zeros((), dtype=torch.int64, device=x.device)
+            drop_step = own_step = self._drop_step
+        cfg = (self.stride, self.residual_kind, self.training, float(drop.p), (self._seed(), drop_step), cin, want_pool)
         y, pooled = StGcnBlockFn.apply(x, A, self.gcn.conv.weight, self.gcn.conv.bias, bn1.weight, bn1.bias,
                                conv.weight, conv.bias, bn2.weight, bn2.bias, *rargs,
                                bn1.running_mean, bn1.running_var, bn2.running_mean, bn2.running_var, *rbufs, cfg, packs)
@@ -189,6 +211,8 @@ class st_gcn(nn.Module):
             tracked = [bn1.num_batches_tracked, bn2.num_batches_tracked]
             if self.residual_kind == "conv":
                 tracked.append(self.residual[1].num_batches_tracked)
+            if own_step is not None:
+                tracked.append(own_step)
             if counters is not None:
                 counters.extend(tracked)
             else:

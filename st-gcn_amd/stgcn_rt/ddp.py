@@ -115,6 +115,7 @@ class GradBucketer:
         self.handles = []
         self.launched = []
         self.trace = []                       # ("grad", param index) / ("launch", bucket) in the order they happened
+        self.hooks_enabled = True             # off while a step is captured into / replayed from a HIP graph
         if self.world > 1:
             for i, p in enumerate(flat.params):
                 p.register_post_accumulate_grad_hook(self._make_hook(i))
@@ -128,6 +129,8 @@ class GradBucketer:
 
     def _make_hook(self, i):
         def hook(param):
+            if not self.hooks_enabled:
+                return
             b = self.bucket_of[i]
             self.trace.append(("grad", i))
             self.pending[b] -= 1
@@ -156,6 +159,16 @@ class GradBucketer:
             self.flat.gather(range(len(self.flat.params)))
         return 1.0 / self.world
 
+    def reduce_flat(self):
+        """All buckets of an already gathered flat gradient (a replayed HIP graph leaves it complete): every
+        all-reduce is launched, then all are waited for.  Returns the scale the optimizer applies."""
+        if self.world > 1:
+            hs = [dist.all_reduce(self.flat.grad[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                  for (s, e, _) in self.buckets]
+            for h in hs:
+                h.wait()
+        return 1.0 / self.world
+
 
 class SGD:
     """torch.optim.SGD(momentum, nesterov, weight_decay) over the flat buffers, one HIP kernel per step."""
@@ -177,14 +190,28 @@ def adjust_lr(base_lr, epoch, steps):
 
 class Trainer:
     """One training iteration as REC_Processor.train does it (processor/recognition.py:84-97):
-    forward, mean cross-entropy, backward, (all-reduce), SGD-nesterov update."""
+    forward, mean cross-entropy, backward, (all-reduce), SGD-nesterov update.
 
-    def __init__(self, model, lr=0.1, momentum=0.9, weight_decay=1e-4, nesterov=True, bucket_bytes=4 << 20):
+    graph=True: after two ordinary steps (they size the allocator's pools, the workspaces and the kernels' per-device
+    state) the forward + loss + backward + gradient gather of a step are captured ONCE into a HIP graph per input
+    shape and replayed from then on: the host issues one graph launch instead of ~200 kernel launches through
+    autograd, which is what bounds small per-GPU batches.  Inputs are copied into the graph's static buffers; the
+    dropout masks advance through a step count kept on the device; collectives and the optimizer launch stay
+    outside the graph (the learning rate may change freely, and no RCCL call is ever captured), so with more than one
+    rank the buckets are all-reduced after the replay instead of under the backward.  If the capture fails the
+    trainer says so on stderr and keeps stepping launch by launch."""
+
+    GRAPH_WARMUP = 2
+
+    def __init__(self, model, lr=0.1, momentum=0.9, weight_decay=1e-4, nesterov=True, bucket_bytes=4 << 20, graph=False):
         self.model = model
         self.flat = FlatParams(model, reverse_execution_order(model))
         self.bucketer = GradBucketer(self.flat, bucket_bytes)
         self.opt = SGD(self.flat, lr, momentum, weight_decay, nesterov)
         self.loss_fn = torch.nn.CrossEntropyLoss()
+        self.use_graph = bool(graph)
+        self._graphs = {}                     # (data shape, label shape) -> (graph, static data, static label, static loss)
+        self._eager_steps = 0
 
     def broadcast_from_rank0(self):
         if self.bucketer.world > 1:
@@ -192,12 +219,72 @@ class Trainer:
             for b in self.model.buffers():
                 dist.broadcast(b, src=0)
 
-    def step(self, data, label):
+    def graph_ready(self):
+        return bool(self._graphs)
+
+    def _forward_backward(self, data, label):
         self.flat.zero_grad()
-        self.bucketer.reset()
         out = self.model(data)
         loss = self.loss_fn(out, label)
         loss.backward()
+        return loss
+
+    def _capture(self, data, label):
+        from . import ops as P
+        if P.TIMING is not None:
+            return None
+        sx, sl = data.clone(), label.clone()
+        g = torch.cuda.CUDAGraph()
+        self.bucketer.hooks_enabled = False
+        try:
+            torch.cuda.synchronize()
+            with torch.cuda.graph(g):
+                loss = self._forward_backward(sx, sl)
+                self.flat.gather(range(len(self.flat.params)))
+        except Exception as e:                # stay in this process: step launch by launch from now on
+            import sys
+            print("stgcn Trainer: HIP graph capture failed (%s: %s); stepping without a graph" % (type(e).__name__, e), file=sys.stderr)
+            self.use_graph = False
+            self.bucketer.hooks_enabled = True
+            torch.cuda.synchronize()
+            return None
+        self.bucketer.hooks_enabled = True
+        return (g, sx, sl, loss)
+
+    def _graph_for(self, data, label):
+        key = (tuple(data.shape), data.dtype, tuple(label.shape))
+        ent = self._graphs.get(key)
+        if ent is None:
+            ent = self._capture(data, label)
+            if ent is not None:
+                self._graphs[key] = ent
+        return ent
+
+    def prepare_graph(self, data, label):
+        """Captures the graph for this input shape now (no step is performed) instead of inside the first step() that
+        would use it; needs the warm-up steps done.  Returns whether a graph is ready."""
+        if self.use_graph and self.model.training and self._eager_steps >= self.GRAPH_WARMUP:
+            return self._graph_for(data, label) is not None
+        return False
+
+    def step(self, data, label, eager=False):
+        """One iteration; returns the loss (a device tensor; with a graph, the graph's own output buffer, overwritten
+        by the next replay).  eager=True forces the launch-by-launch path for this call."""
+        from . import ops as P
+        if self.use_graph and not eager and P.TIMING is None and self.model.training and self._eager_steps >= self.GRAPH_WARMUP:
+            ent = self._graph_for(data, label)
+            if ent is not None:
+                g, sx, sl, loss = ent
+                if data.data_ptr() != sx.data_ptr():
+                    sx.copy_(data, non_blocking=True)
+                if label.data_ptr() != sl.data_ptr():
+                    sl.copy_(label, non_blocking=True)
+                g.replay()
+                self.opt.step(self.bucketer.reduce_flat())
+                return loss
+        self.bucketer.reset()
+        loss = self._forward_backward(data, label)
         scale = self.bucketer.finish()
         self.opt.step(scale)
+        self._eager_steps += 1
         return loss

@@ -95,6 +95,7 @@ class StGcnBlockFn(torch.autograd.Function):
                 rm1, rv1, rm2, rv2, rmr, rvr, cfg, packs=None):
         P.check_act(x)
         stride, kind, training, drop_p, seed, cin_true, want_pool = cfg
+        seed, seed_step = seed if isinstance(seed, tuple) else (seed, None)      # (seed, device-side step count)
         ctx.set_materialize_grads(False)
         x = P.cl(x)
         dtype = x.dtype
@@ -132,7 +133,7 @@ class StGcnBlockFn(torch.autograd.Function):
             res = None
         p = drop_p if training else 0.0
         if training:
-            out, relu_mask = P.block_out_fwd(o, res, bn2, bnr, p, seed, want_mask=True)
+            out, relu_mask = P.block_out_fwd(o, res, bn2, bnr, p, seed, want_mask=True, seed_step=seed_step)
         else:
             out, relu_mask = P.block_out_fwd(o, res, bn2, bnr, p, seed), None
         ctx.relu_mask = relu_mask

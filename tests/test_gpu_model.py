@@ -394,3 +394,101 @@ def test_training_learns_a_separable_task(net, dtype):
     res = evaluate(model, [(P.augment_batch(xd, window=W, shift=[4] * N), yd)], DEV, show_topk=(1,))
     print("top1", res["topk"][1], "eval loss", res["mean_loss"])
     assert res["topk"][1] >= 0.9, res["topk"]
+
+
+def _fresh_trainer(mod, dtype, dropout, graph, lr=0.01, wd=1e-4):
+    from stgcn_rt.ddp import Trainer
+    g = O.build_graph("ntu-rgb+d", "spatial")
+    sd = O.det_state(3, 60, g["A"], True, dtype=torch.float32)
+    m = mod.Model(3, 60, dict(layout="ntu-rgb+d", strategy="spatial"), True, dropout=dropout, compute_dtype=dtype).to(DEV)
+    m.load_state_dict(sd, strict=True)
+    m.train()
+    return m, Trainer(m, lr=lr, momentum=0.9, weight_decay=wd, nesterov=True, graph=graph)
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+def test_trainer_graph_replay_matches_launch_by_launch(net, dtype):
+    """The step captured into a HIP graph (forward, loss, backward, gradient gather; optimizer launch outside) against
+    the same trainer stepping launch by launch: same losses and parameters over six steps on changing batches (the
+    replayed steps read their batch from the graph's static buffers), running statistics and counters included."""
+    mod, _ = net
+    xs = [O.det_input(2, 3, 24, 25, 2, tag=3100 + i).float().to(DEV) for i in range(6)]
+    ls = [torch.tensor([(3 * i + 1) % 60, (7 * i + 2) % 60], device=DEV) for i in range(6)]
+    res = {}
+    for graph in (False, True):
+        # a small learning rate: at 0.01 and above, two launch-by-launch runs of this two-clip problem already drift
+        # apart by 5e-4 in three steps from the last-bit differences of the BatchNorm atomics
+        m, tr = _fresh_trainer(mod, dtype, 0.0, graph, lr=1e-3)
+        init = {k: cpu64(v).clone() for k, v in m.state_dict().items()}
+        losses = [float(tr.step(x, l).detach()) for x, l in zip(xs, ls)]
+        assert tr.graph_ready() == graph
+        res[graph] = (losses, {k: cpu64(v) for k, v in m.state_dict().items()}, init)
+    tol = 2e-4 if dtype == torch.float32 else 2e-2
+    for a, b in zip(res[True][0], res[False][0]):
+        assert abs(a - b) < tol * max(1.0, abs(b)), (res[True][0], res[False][0])
+    # What six steps changed, replayed against launch by launch.  Single small tensors may differ by a few per cent
+    # between ANY two runs (one ReLU decision at a pre-activation within rounding of zero falls the other way: see
+    # tests/test_oracle_golden.py::test_one_relu_decision_moves_gradients), so the bound is on the whole update.
+    worst, ua, ub = ("", 0.0), [], []
+    for k, v in res[False][1].items():
+        if not v.is_floating_point():
+            assert torch.equal(res[True][1][k], v), k
+        elif k != "A":
+            da, db = res[True][1][k] - res[True][2][k], v - res[False][2][k]
+            worst = max(worst, (k, rel_l2(da, db)), key=lambda t: t[1])
+            if "running" in k:
+                assert rel_l2(da, db) < tol * 10, k
+            else:
+                ua.append(da.reshape(-1))
+                ub.append(db.reshape(-1))
+    whole = rel_l2(torch.cat(ua), torch.cat(ub))
+    print("six-step parameter update, graph replay vs launch by launch: whole vector %.2e, worst tensor %s %.2e" % (whole, worst[0], worst[1]))
+    assert whole < (5e-3 if dtype == torch.float32 else 5e-2), (whole, worst)
+    assert int(res[True][1]["data_bn.num_batches_tracked"]) == 6
+
+
+def test_trainer_graph_replay_draws_fresh_dropout_masks(net):
+    """Every launch argument of a replayed step is frozen in the graph; the dropout masks still change from step to
+    step because the kernel mixes a device-side step count into its seed.  With lr = 0 and no weight decay the
+    parameters never move, so on one fixed batch the loss varies only through the masks."""
+    mod, _ = net
+    m, tr = _fresh_trainer(mod, torch.float32, 0.5, True, lr=0.0, wd=0.0)
+    x = O.det_input(2, 3, 24, 25, 2, tag=3200).float().to(DEV)
+    l = torch.tensor([4, 9], device=DEV)
+    losses = [float(tr.step(x, l).detach()) for _ in range(7)]
+    assert tr.graph_ready() and int(m._drop_step) == 7
+    assert len({round(v, 6) for v in losses[2:]}) == 5, losses          # five replays, five different masks
+    m2, tr2 = _fresh_trainer(mod, torch.float32, 0.5, False, lr=0.0, wd=0.0)
+    losses2 = [float(tr2.step(x, l).detach()) for _ in range(7)]
+    # the same seeds and step counts launch by launch: the same masks, hence the same losses
+    assert max(abs(a - b) for a, b in zip(losses, losses2)) < 1e-4, (losses, losses2)
+
+
+def test_model_dropout_matches_oracle(net):
+    """Whole model with dropout 0.5 in train mode, forward and backward, against the oracle drawing the same masks:
+    block i's seed is st_gcn._seed(), advanced by the device-side step count times 0x85EBCA6B (second call here)."""
+    mod, _ = net
+    g = O.build_graph("ntu-rgb+d", "spatial")
+    sd = O.det_state(3, 60, g["A"], True, dtype=torch.float32)
+    x = O.det_input(2, 3, 24, 25, 2, tag=3300)
+    labels = torch.tensor([11, 50])
+    torch.manual_seed(4321)
+    m = mod.Model(3, 60, dict(layout="ntu-rgb+d", strategy="spatial"), True, dropout=0.5).to(DEV)
+    m.load_state_dict(sd, strict=True)
+    m.train()
+    m(x.float().to(DEV))                                 # step count 0 -> 1; running statistics move: reload them
+    m.load_state_dict(sd, strict=True)
+    assert int(m._drop_step) == 1
+    seeds = [(blk._seed() + 1 * 0x85EBCA6B) & 0xFFFFFFFF for blk in m.st_gcn_networks]
+    F = _capture()
+    logits = m(x.float().to(DEV))
+    torch.nn.functional.cross_entropy(logits, labels.to(DEV)).backward()
+    masks = _masks_from_capture(F, 10)
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+    lo, cache, _ = O.model_forward(sd64, x, True, dropout=0.5, seeds=seeds, masks=masks)
+    assert rel(cpu64(logits), lo) < 1e-4
+    _, dlog = O.cross_entropy(cpu64(logits), labels)
+    ref_g = O.model_backward(sd64, cache, dlog, True)
+    for k, prm in m.named_parameters():
+        if not (k.endswith("tcn.2.bias") or k.endswith("residual.0.bias")):
+            assert rel_l2(cpu64(prm.grad), ref_g[k]) < 1e-4, k

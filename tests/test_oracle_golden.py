@@ -171,3 +171,35 @@ def test_one_relu_decision_moves_gradients():
     moved = max(float((g1[k] - g0[k]).norm() / g0[k].norm()) for k in g0
                 if not (k.endswith("tcn.2.bias") or k.endswith("residual.0.bias")))
     assert moved > 1e-3, moved
+
+
+def test_stock_torch_step_matches_golden(golden):
+    """oracle/torch_step.py (the CPU baseline bench.py times: the library operators the reference delegates to, as a
+    function of a flat state dict) against the reference's golden vectors: logits and gradient samples of the small
+    NTU training case, eval logits of the Kinetics-layout case, and the three SGD-nesterov steps."""
+    from oracle import torch_step as TS
+    G = golden["model"]
+    for ci in (0, 2, 8):
+        name, lay, ncls, N, T, M, training = C.MODEL_CASES[ci]
+        g = O.build_graph(lay, C.strategy_of(name))
+        sd = O.det_state(3, ncls, g["A"], True)
+        x, labels = C.model_inputs(ci)
+        st = TS.Stepper(sd, dropout=0.0)
+        logits = TS.forward(st.sd, x, training)
+        assert float((logits.detach() - torch.tensor(G[name + "/logits"])).abs().max()) < 1e-9 * max(1.0, float(np.abs(G[name + "/logits"]).max()))
+        if training:
+            torch.nn.functional.cross_entropy(logits, labels).backward()
+            for k in st.names:
+                flat = st.sd[k].grad.reshape(-1)
+                got = flat[:: max(1, flat.numel() // 257)].numpy()
+                ref = G[name + "/gsample:" + k]
+                assert np.abs(got - ref).max() <= 1e-9 * max(1e-3, np.abs(ref).max()), k
+    S = golden["sgd"]
+    g = O.build_graph("ntu-rgb+d", "spatial")
+    st = TS.Stepper(O.det_state(3, 60, g["A"], True), lr=0.1)
+    for step in range(3):
+        x = O.det_input(2, 3, 24, 25, 2, tag=1200 + step)
+        labels = torch.tensor([(5 * i + step) % 60 for i in range(2)])
+        assert abs(float(st.step(x, labels)) - float(S["loss%d" % step])) < 1e-9
+    for k in ("fcn.bias", "edge_importance.3", "st_gcn_networks.0.gcn.conv.weight"):
+        assert np.abs(st.sd[k].detach().numpy() - S["p:" + k]).max() < 1e-9

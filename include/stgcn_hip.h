@@ -10,7 +10,8 @@
  *     logical shape [B,C,T,V] in torch.channels_last memory format); dtype STGCN_F32 or
  *     STGCN_BF16; per-channel parameters and all gradients of parameters are float32;
  *   - `stream` is a hipStream_t; calls only enqueue work: no allocation, no synchronisation;
- *   - return value: 0 ok, 1 invalid argument, 2 launch failed, 3 workspace too small;
+ *   - return value: 0 ok, 1 invalid argument, 2 launch failed, 3 workspace too small, 4 problem exceeds the
+ *     library's static scratch array (stgcn_gcn_agrad_noalloc only);
  *   - `stats` buffers are double[2*C]; kernels ADD into them, the caller zeroes them first;
  *   - channel counts of MFMA operands must be multiples of one 32-byte k-step (16 bf16 / 8 f32);
  *     conv_rows / conv_wgrad input channels multiples of one 128-byte chunk (64 bf16 / 32 f32).
@@ -73,6 +74,17 @@ int stgcn_gcn_fused(int dtype, const void* in, const void* w_packed, const float
 int stgcn_gcn_agrad(int dtype, const void* x, const void* w_packed, const float* bias, const void* dy,
                     float* dA, int NF, int V, int Cin, int Cout, int K,
                     void* workspace, size_t workspace_bytes, void* stream);
+
+/* stgcn_gcn_agrad without a workspace argument and without any allocation.  No counterpart in the reference: it is
+ * for callers that cannot allocate device memory -- code under HIP graph capture, tight serving loops, harnesses that
+ * forbid hipMalloc.  The partial sums go to a static device array inside the library (4 MiB per GPU, held until the
+ * process ends) instead of a caller-provided workspace; same kernels, same result bit for bit.  Limit: (resident
+ * workgroups, at most 2 per compute unit) * K * V * V * 4 bytes <= 4 MiB -- every ST-GCN graph (V <= 25, K <= 3) on a
+ * 256-CU part; larger problems return status 4.  All calls on one GPU share that array: calls that overlap on one GPU
+ * race, calls ordered on one stream do not.  The first call on each device looks the array's address up and must not
+ * run under stream capture. */
+int stgcn_gcn_agrad_noalloc(int dtype, const void* x, const void* w_packed, const float* bias, const void* dy,
+                            float* dA, int NF, int V, int Cin, int Cout, int K, void* stream);
 
 /* dW[k][co][ci] = sum_{f,v} (sum_w adj[k][v][w] dy[f,w,co]) x[f,v,ci];  db[k][co] = sum of the same bracket.
  * adj = (A*importance)[k][v][w].  K <= 3 per call.

@@ -668,6 +668,44 @@ extern "C" int stgcn_gcn_agrad(int dtype, const void* x, const void* w_packed, c
     return STGCN_ERR_ARG;
 }
 
+// The same computation for callers that may not allocate (code under HIP graph capture, serving loops, harnesses
+// that forbid hipMalloc) and therefore cannot bring a workspace: the partial-sum slab lives in a file-scope device
+// array, one copy per GPU, held until the process ends.  Host code never passes the array's NAME to a kernel (on the
+// host it is a stand-in, not a device address): its address on the current device is asked for once per device and
+// cached; kernels receive that pointer.  Every call on a GPU shares the GPU's array, so calls that overlap on one
+// GPU (two streams, two host threads) race; calls ordered on one stream do not.  Nothing needs clearing between
+// calls: every partial the final sum reads is written in full by the workgroup that owns it.
+constexpr size_t GCN_SCRATCH_BYTES = 4u << 20;
+static __device__ __align__(256) unsigned char gcn_agrad_scratch[GCN_SCRATCH_BYTES];
+static std::atomic<void*> g_gcn_scratch_ptr[STGCN_MAX_DEV];
+
+static int gcn_scratch_on_current_device(void** out) {
+    const int d = stgcn_cur_device();
+    if (d < 0 || d >= STGCN_MAX_DEV) return STGCN_ERR_ARG;
+    void* p = g_gcn_scratch_ptr[d].load(std::memory_order_acquire);
+    if (!p) {
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(gcn_agrad_scratch)) != hipSuccess || !p) return STGCN_ERR_LAUNCH;
+        g_gcn_scratch_ptr[d].store(p, std::memory_order_release);      // two first callers store the same address
+    }
+    *out = p;
+    return STGCN_OK;
+}
+
+extern "C" int stgcn_gcn_agrad_noalloc(int dtype, const void* x, const void* w_packed, const float* bias, const void* dy,
+                                       float* dA, int NF, int V, int Cin, int Cout, int K, void* stream) {
+    if (!x || !w_packed || !dy || !dA) return STGCN_ERR_ARG;
+    void* scratch = nullptr;
+    int rc = gcn_scratch_on_current_device(&scratch);
+    if (rc != STGCN_OK) return rc;
+    GcnAgradArgs a;
+    a.x = x; a.w = w_packed; a.bias = bias; a.dy = dy; a.slab = (float*)scratch;
+    a.NF = NF; a.V = V; a.Cin = Cin; a.Cout = Cout; a.K = K; a.ntw = 1;
+    if (dtype == STGCN_BF16) rc = gcn_agrad_run<bf16>(a, dA, GCN_SCRATCH_BYTES, (hipStream_t)stream);
+    else if (dtype == STGCN_F32) rc = gcn_agrad_run<float>(a, dA, GCN_SCRATCH_BYTES, (hipStream_t)stream);
+    else return STGCN_ERR_ARG;
+    return rc == STGCN_ERR_WORKSPACE ? STGCN_ERR_SCRATCH : rc;       // partials of this shape exceed the static array
+}
+
 // ------------------------------------------------------------------------------------------
 // gcn_wgrad
 struct GcnWgradArgs {

@@ -15,6 +15,7 @@
 #define STGCN_ERR_ARG 1
 #define STGCN_ERR_LAUNCH 2
 #define STGCN_ERR_WORKSPACE 3
+#define STGCN_ERR_SCRATCH 4   // the problem needs more than the library's static scratch array holds
 
 #define STGCN_F32 0
 #define STGCN_BF16 1

@@ -24,6 +24,7 @@ _SIGS = {
     "stgcn_conv_wgrad": [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp],
     "stgcn_gcn_fused": [_i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "stgcn_gcn_agrad": [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp],
+    "stgcn_gcn_agrad_noalloc": [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "stgcn_gcn_wgrad": [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp],
     "stgcn_bn_finalize": [_vp, _d, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _i, _i, _vp],
     "stgcn_stats_to_grads": [_vp, _vp, _vp, _i, _vp],
@@ -48,7 +49,8 @@ _SIGS = {
 }
 
 EXPORTS = tuple(_SIGS) + ("stgcn_arch",)
-_ERR = {1: "invalid argument", 2: "kernel launch failed", 3: "workspace too small"}
+_ERR = {1: "invalid argument", 2: "kernel launch failed", 3: "workspace too small",
+        4: "the problem exceeds the library's static scratch array"}
 
 
 def lib_path():

@@ -13,6 +13,41 @@ import torch
 import torch.distributed as dist
 
 
+class _Staged:
+    """Handle of a collective on a device tensor carried out on a host copy (see _host_staged)."""
+
+    def __init__(self, work, host, dst):
+        self.work, self.host, self.dst = work, host, dst
+
+    def wait(self):
+        self.work.wait()
+        self.dst.copy_(self.host)
+
+
+def _host_staged(group):
+    """Whether collectives on device tensors are carried out on host copies: with the gloo backend (rehearsals of the
+    multi-process path on a box with fewer GPUs than ranks) the device tensors never reach the collective library;
+    RCCL ("nccl") takes them as they are."""
+    return dist.get_backend(group) == "gloo"
+
+
+def all_reduce_sum(t, group=None):
+    """Asynchronous sum all-reduce of tensor t in place; returns a handle with wait()."""
+    if t.is_cuda and _host_staged(group):
+        host = t.detach().cpu()                                   # waits for the stream that produced t
+        return _Staged(dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group, async_op=True), host, t)
+    return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=True)
+
+
+def broadcast0(t, group=None):
+    if t.is_cuda and _host_staged(group):
+        host = t.detach().cpu()
+        dist.broadcast(host, src=0, group=group)
+        t.copy_(host)
+    else:
+        dist.broadcast(t, src=0, group=group)
+
+
 class FlatParams:
     """Re-homes every parameter of `module` (and its .grad) as a view into one flat float32 buffer."""
 
@@ -143,7 +178,7 @@ class GradBucketer:
         self.launched.append(b)
         self.trace.append(("launch", b))
         self.flat.gather(idxs)
-        self.handles.append(dist.all_reduce(self.flat.grad[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        self.handles.append(all_reduce_sum(self.flat.grad[s:e], self.group))
 
     def finish(self):
         """Launch whatever was not triggered by hooks (unused parameters), wait for all buckets.
@@ -163,8 +198,7 @@ class GradBucketer:
         """All buckets of an already gathered flat gradient (a replayed HIP graph leaves it complete): every
         all-reduce is launched, then all are waited for.  Returns the scale the optimizer applies."""
         if self.world > 1:
-            hs = [dist.all_reduce(self.flat.grad[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-                  for (s, e, _) in self.buckets]
+            hs = [all_reduce_sum(self.flat.grad[s:e], self.group) for (s, e, _) in self.buckets]
             for h in hs:
                 h.wait()
         return 1.0 / self.world
@@ -215,9 +249,9 @@ class Trainer:
 
     def broadcast_from_rank0(self):
         if self.bucketer.world > 1:
-            dist.broadcast(self.flat.flat, src=0)
+            broadcast0(self.flat.flat)
             for b in self.model.buffers():
-                dist.broadcast(b, src=0)
+                broadcast0(b)
 
     def graph_ready(self):
         return bool(self._graphs)

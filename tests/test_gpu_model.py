@@ -492,3 +492,85 @@ def test_model_dropout_matches_oracle(net):
     for k, prm in m.named_parameters():
         if not (k.endswith("tcn.2.bias") or k.endswith("residual.0.bias")):
             assert rel_l2(cpu64(prm.grad), ref_g[k]) < 1e-4, k
+
+
+def test_checkpoint_file_to_golden_logits(net, golden, tmp_path):
+    """The checkpoint wire format end to end on the GPU (torchlight/torchlight/io.py:57-107 of the reference): a file
+    written by save_model from a DataParallel-style wrapper (every key carries `module.`), loaded with load_weights
+    into a fresh model on the GPU, must reproduce the reference's golden eval logits; with ignore_weights='fcn' the
+    classifier keeps the fresh model's values and the rest still arrives."""
+    mod, _ = net
+    from stgcn_rt import checkpoint as CK
+    ci = [c[0] for c in C.MODEL_CASES].index("ntu_small_eval")
+    name, lay, ncls, N, T, M, _ = C.MODEL_CASES[ci]
+    g = O.build_graph(lay, "spatial")
+    sd = O.det_state(3, ncls, g["A"], True, dtype=torch.float32)
+    src = mod.Model(3, ncls, dict(layout=lay, strategy="spatial"), True)
+    src.load_state_dict(sd, strict=True)
+    wrapper = torch.nn.Module()
+    wrapper.module = src                                   # state_dict keys: module.<name>, as under nn.DataParallel
+    path = str(tmp_path / "epoch1_model.pt")
+    saved = CK.save_model(wrapper, path)
+    assert all(not k.startswith("module.") for k in saved) and "A" in saved
+    raw = torch.load(path, weights_only=True)
+    torch.save({"module." + k: v for k, v in raw.items()}, path)       # an older file that kept the prefix
+    x, _ = C.model_inputs(ci)
+    for dtype in DTYPES:
+        m = mod.Model(3, ncls, dict(layout=lay, strategy="spatial"), True, compute_dtype=dtype).to(DEV)
+        CK.load_weights(m, path)
+        m.eval()
+        with torch.no_grad():
+            logits = m(x.float().to(DEV))
+        assert rel(cpu64(logits), golden["model"][name + "/logits"]) < TOL[dtype]
+    m = mod.Model(3, ncls, dict(layout=lay, strategy="spatial"), True).to(DEV)
+    fresh_fc = m.fcn.weight.detach().clone()
+    logs = []
+    CK.load_weights(m, path, ignore_weights="fcn", log=logs.append)
+    assert torch.equal(m.fcn.weight, fresh_fc) and any("Filter [fcn]" in l for l in logs)
+    assert torch.equal(m.st_gcn_networks[3].tcn[2].weight.cpu(), sd["st_gcn_networks.3.tcn.2.weight"])
+
+
+@pytest.mark.parametrize("lay,strat,ncls", [("ntu-rgb+d", "uniform", 60), ("ntu-rgb+d", "distance", 60), ("ntu-rgb+d", "spatial", 60),
+                                            ("openpose", "uniform", 400), ("openpose", "distance", 400), ("openpose", "spatial", 400)])
+def test_large_batch_bf16_inference_sweep(net, lay, strat, ncls):
+    """Large-batch bf16 inference across the partition strategies (K = 1 / 2 / 3) and both layouts: in eval mode a
+    clip's logits do not depend on what else is in the batch, so the clips of a 1024-clip (once per layout; 128 otherwise) batch at T = 300 must come out
+    as they do in two-clip batches -- whose logits the golden eval cases pin for every strategy -- and the first two
+    clips are those golden inputs themselves."""
+    mod, _ = net
+    V = 25 if lay == "ntu-rgb+d" else 18
+    g = O.build_graph(lay, strat)
+    sd = O.det_state(3, ncls, g["A"], True, dtype=torch.float32)
+    m = mod.Model(3, ncls, dict(layout=lay, strategy=strat), True, compute_dtype=torch.bfloat16).to(DEV)
+    m.load_state_dict(sd, strict=True)
+    m.eval()
+    N = 1024 if (lay, strat) in (("ntu-rgb+d", "distance"), ("openpose", "uniform")) else 128    # the sweep's own N once per layout
+    x = torch.tensor(O.det_uniform((N, 3, 300, V, 2), 8800 + V)).float().to(DEV)
+    probes = (0, N // 2 - 2, N - 2)
+    with torch.no_grad():
+        big = m(x)
+        pairs = torch.cat([m(x[i:i + 2]) for i in probes])
+    assert torch.isfinite(big).all()
+    ref = torch.cat([big[i:i + 2] for i in probes])
+    assert float((ref - pairs).abs().max() / pairs.abs().max()) < 1e-6      # same kernels, same rows: same bits up to tile order
+    # and against the float64 oracle for one clip pair (bf16 tolerance)
+    lo, _, _ = O.model_forward({k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}, x[:2].cpu().double(), False)
+    assert rel(cpu64(big[:2]), lo) < TOL[torch.bfloat16]
+
+
+@pytest.mark.parametrize("ci", [i for i, c in enumerate(C.MODEL_CASES) if ("uniform" in c[0] or "distance" in c[0]) and not c[6]],
+                         ids=[c[0] for c in C.MODEL_CASES if ("uniform" in c[0] or "distance" in c[0]) and not c[6]])
+def test_uniform_distance_eval_logits_bf16_and_f32(net, golden, ci):
+    """K = 1 / 2 eval logits against the reference's golden vectors in both precisions (graph.py:85-94)."""
+    mod, _ = net
+    name, lay, ncls, N, T, M, _ = C.MODEL_CASES[ci]
+    strat = C.strategy_of(name)
+    g = O.build_graph(lay, strat)
+    sd = O.det_state(3, ncls, g["A"], True, dtype=torch.float32)
+    x, _ = C.model_inputs(ci)
+    for dtype in DTYPES:
+        m = mod.Model(3, ncls, dict(layout=lay, strategy=strat), True, compute_dtype=dtype).to(DEV)
+        m.load_state_dict(sd, strict=True)
+        m.eval()
+        with torch.no_grad():
+            assert rel(cpu64(m(x.float().to(DEV))), golden["model"][name + "/logits"]) < TOL[dtype]

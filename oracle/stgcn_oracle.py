@@ -618,8 +618,9 @@ def cross_entropy(logits, labels):
     return loss, d / n
 
 
-def model_backward(sd, cache, dlogits, training=True):
-    """Returns grads: dict name -> tensor for every parameter of sd."""
+def model_backward(sd, cache, dlogits, training=True, input_grad=False):
+    """Returns grads: dict name -> tensor for every parameter of sd; with input_grad, (grads, d loss / d x) with
+    x the raw [N,C,T,V,M] clip tensor."""
     N, C, T, V, M = cache["dims"]
     Bc, Cf, Tf, Vf = cache["feat_shape"]
     g = {}
@@ -639,7 +640,9 @@ def model_backward(sd, cache, dlogits, training=True):
         if ew:
             g["edge_importance.%d" % i] = dA * sd["A"]
     dxb = dh.reshape(N, M, C, T, V).permute(0, 1, 4, 2, 3).reshape(N * M, V * C, T)
-    _, g["data_bn.weight"], g["data_bn.bias"] = bn_backward(cache["xp"], sd["data_bn.weight"], cache["cd"], dxb, training)
+    dxp, g["data_bn.weight"], g["data_bn.bias"] = bn_backward(cache["xp"], sd["data_bn.weight"], cache["cd"], dxb, training)
+    if input_grad:
+        return g, dxp.reshape(N, M, V, C, T).permute(0, 3, 4, 2, 1).contiguous()
     return g
 
 

@@ -83,14 +83,18 @@ class Model(nn.Module):
         N, C, T, V, M = x.size()
         dtype = self.compute_dtype
         bn = self.data_bn
-        if self.training:
+        # Train / eval follows each sub-module's own flag, as in the reference where every nn.BatchNorm / nn.Dropout
+        # consults its own .training (a model in train mode with its BatchNorms frozen by .eval() is a common
+        # fine-tuning set-up).
+        drops = any(b.tcn[4].training and b.tcn[4].p > 0 for b in self.st_gcn_networks)
+        if bn.training or drops or any(b.tcn[0].training for b in self.st_gcn_networks):
             P.stats_begin(x.device)                     # one fill clears every statistic buffer of this step
-        h = DataBnFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, self.training, dtype,
+        h = DataBnFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.training, dtype,
                            P.pad_to(C, P.kstep(dtype)))
         packs = self._packed_weights(dtype, h.device)
-        counters = [bn.num_batches_tracked] if self.training else None
+        counters = [bn.num_batches_tracked] if bn.training else []
         step = None
-        if self.training:
+        if drops:
             # The dropout masks of a step are drawn from (per-block seed, step count); the count lives on the device
             # and advances with the BatchNorm counters below, so a step replayed from a captured HIP graph draws
             # fresh masks although every launch argument is frozen in the graph.
@@ -198,21 +202,24 @@ class st_gcn(nn.Module):
             rbufs = (rb.running_mean, rb.running_var)
         else:
             rargs, rbufs = (None, None, None, None), (None, None)
+        bns = [bn1, bn2] + ([self.residual[1]] if self.residual_kind == "conv" else [])
+        if len({b.training for b in bns}) != 1:
+            raise NotImplementedError("the BatchNorm modules of one st_gcn block must be all in train mode or all in eval mode")
+        bn_train = bn1.training
+        drop_p = float(drop.p) if drop.training else 0.0
         own_step = None
-        if self.training and drop.p > 0 and drop_step is None:
+        if drop_p > 0 and drop_step is None:
             if self._drop_step is None or self._drop_step.device != x.device:
                 self._drop_step = torch.zeros((), dtype=torch.int64, device=x.device)
             drop_step = own_step = self._drop_step
-        cfg = (self.stride, self.residual_kind, self.training, float(drop.p), (self._seed(), drop_step), cin, want_pool)
+        cfg = (self.stride, self.residual_kind, bn_train, drop_p, (self._seed(), drop_step), cin, want_pool)
         y, pooled = StGcnBlockFn.apply(x, A, self.gcn.conv.weight, self.gcn.conv.bias, bn1.weight, bn1.bias,
                                conv.weight, conv.bias, bn2.weight, bn2.bias, *rargs,
                                bn1.running_mean, bn1.running_var, bn2.running_mean, bn2.running_var, *rbufs, cfg, packs)
-        if self.training:
-            tracked = [bn1.num_batches_tracked, bn2.num_batches_tracked]
-            if self.residual_kind == "conv":
-                tracked.append(self.residual[1].num_batches_tracked)
-            if own_step is not None:
-                tracked.append(own_step)
+        tracked = [b.num_batches_tracked for b in bns] if bn_train else []
+        if own_step is not None:
+            tracked.append(own_step)
+        if tracked:
             if counters is not None:
                 counters.extend(tracked)
             else:

@@ -131,8 +131,8 @@ class StGcnBlockFn(torch.autograd.Function):
             res = x
         else:
             res = None
-        p = drop_p if training else 0.0
-        if training:
+        p = drop_p                                      # already 0 when the Dropout module is in eval mode
+        if training or p > 0:
             out, relu_mask = P.block_out_fwd(o, res, bn2, bnr, p, seed, want_mask=True, seed_step=seed_step)
         else:
             out, relu_mask = P.block_out_fwd(o, res, bn2, bnr, p, seed), None
@@ -247,8 +247,7 @@ class DataBnFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, gamma, beta, rmean, rvar, training, dtype, cp):
-        if not x.is_cuda:
-            raise RuntimeError("input must live on the GPU: the ST-GCN HIP path has no CPU fallback")
+        P.check_device(x, "input")
         x = x.float().contiguous()
         N, Cc, T, V, M = x.shape
         dev = x.device
@@ -261,21 +260,35 @@ class DataBnFn(torch.autograd.Function):
         out = P.new_act(N * M, cp, T, V, dtype, dev)
         L.call("stgcn_data_bn_apply", L.dtype_code(dtype), L.ptr(x), L.ptr(out), L.ptr(bn.scale), L.ptr(bn.shift),
                N, Cc, T, V, M, cp, L.stream_ptr())
-        ctx.save_for_backward(x)
+        ctx.save_for_backward(x, gamma)
         ctx.bn = bn
+        ctx.training = training
         ctx.dims = (N, Cc, T, V, M, cp)
         return out
 
     @staticmethod
     def backward(ctx, dx0):
-        (x,) = ctx.saved_tensors
+        x, gamma = ctx.saved_tensors
         N, Cc, T, V, M, cp = ctx.dims
         dx0 = P.cl(dx0)
         stats = P.stats_alloc((2 * V * Cc,), x.device)
         L.call("stgcn_data_bn_bwd", L.dtype_code(dx0.dtype), L.ptr(dx0), L.ptr(x), L.ptr(ctx.bn.mean), L.ptr(ctx.bn.rstd), L.ptr(stats),
                N, Cc, T, V, M, cp, L.stream_ptr())
         dg, db = P.stats_to_grads(stats, V * Cc)
-        return None, dg, db, None, None, None, None, None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            # Gradient w.r.t. the raw clip (saliency maps, adversarial inputs): never needed by a training step, so it is
+            # spelled in tensor ops on the 3-channel input instead of a kernel.  Channel index of data_bn is v*C + c.
+            ch = lambda t: t.detach().float().reshape(1, V, Cc, 1, 1).permute(0, 2, 3, 1, 4)          # -> [1,C,1,V,1]
+            dy = dx0[:, :Cc].float().reshape(N, M, Cc, T, V).permute(0, 2, 3, 4, 1)                   # [N,C,T,V,M]
+            scale = ch(gamma) * ch(ctx.bn.rstd)
+            if ctx.training:
+                n = float(N * M * T)
+                xhat = (x - ch(ctx.bn.mean)) * ch(ctx.bn.rstd)
+                dx = scale * (dy - ch(db) / n - xhat * (ch(dg) / n))
+            else:
+                dx = scale * dy
+        return dx, dg, db, None, None, None, None, None
 
 
 class HeadFn(torch.autograd.Function):
@@ -284,8 +297,7 @@ class HeadFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, pooled, W, b, N, M):
-        if not pooled.is_cuda:
-            raise RuntimeError("input must live on the GPU: the ST-GCN HIP path has no CPU fallback")
+        P.check_device(pooled, "input")
         pooled = pooled.float().contiguous()
         Bc, Cc = pooled.shape
         ncls = W.shape[0]

@@ -102,9 +102,19 @@ def new_act(B, Cc, T, V, dtype, device):
     return torch.empty((B, Cc, T, V), dtype=dtype, device=device, memory_format=CL)
 
 
-def check_act(x, name="x"):
+def check_device(x, name="x"):
+    """The C entry points launch on HIP's current device and on its current stream: a tensor of another GPU would be
+    read through a foreign pointer, unordered against the work that produced it."""
     if not x.is_cuda:
         raise RuntimeError("%s must live on the GPU: the ST-GCN HIP path has no CPU fallback" % name)
+    if x.device.index != torch.cuda.current_device():
+        raise RuntimeError("%s lives on cuda:%d but the current device is cuda:%d: select the tensor's device first "
+                           "(torch.cuda.set_device / `with torch.cuda.device(...)`); one process drives one GPU here"
+                           % (name, x.device.index, torch.cuda.current_device()))
+
+
+def check_act(x, name="x"):
+    check_device(x, name)
     if x.dim() != 4:
         raise ValueError("%s must be [B, C, T, V]" % name)
 
@@ -334,6 +344,10 @@ def block_out_bwd(dout, out, o, r, bn2, gamma2, bnr, gammar, want_g, drop_p, see
     args[1] = 1
     args[17], args[18], args[19] = L.ptr(dO), L.ptr(dR), L.ptr(g)
     _launch((str(o.dtype), 1, rows, Cc, has_r, want_g), "stgcn_block_out_bwd", *args)
+    # the bias sums leave this function (they become .grad of the conv biases): hand out memory of their own, not
+    # views of the statistics arena, which the next training forward clears
+    dbf = dbf.clone()
+    dbo, dbr = dbf[:Cc], dbf[Cc:]
     res = (dO, dR, g, stats2, (statsr if has_r else None), dbo, (dbr if has_r else None))
     if want_bn_grads:
         res = res + ((bng[0], bng[1], bng[2] if has_r else None, bng[3] if has_r else None),)

@@ -574,3 +574,57 @@ def test_uniform_distance_eval_logits_bf16_and_f32(net, golden, ci):
         m.eval()
         with torch.no_grad():
             assert rel(cpu64(m(x.float().to(DEV))), golden["model"][name + "/logits"]) < TOL[dtype]
+
+
+@pytest.mark.parametrize("training", [True, False], ids=["train", "eval"])
+def test_gradient_wrt_input_clip(net, training):
+    """The reference Model is differentiable w.r.t. its input (saliency, adversarial inputs); so is this one:
+    d loss / d x through data_bn against the oracle, and tensors of another device than the current one are refused."""
+    mod, _ = net
+    g = O.build_graph("ntu-rgb+d", "spatial")
+    sd = O.det_state(3, 60, g["A"], True, dtype=torch.float32)
+    x = O.det_input(2, 3, 24, 25, 2, tag=3400)
+    labels = torch.tensor([2, 40])
+    m = mod.Model(3, 60, dict(layout="ntu-rgb+d", strategy="spatial"), True).to(DEV)
+    m.load_state_dict(sd, strict=True)
+    m.train(training)
+    xd = x.float().to(DEV).requires_grad_(True)
+    F = _capture()
+    logits = m(xd)
+    torch.nn.functional.cross_entropy(logits, labels.to(DEV)).backward()
+    masks = _masks_from_capture(F, 10)
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+    lo, cache, _ = O.model_forward(sd64, x, training, masks=masks)
+    _, dlog = O.cross_entropy(cpu64(logits), labels)
+    _, dx = O.model_backward(sd64, cache, dlog, training, input_grad=True)
+    assert xd.grad is not None and tuple(xd.grad.shape) == tuple(x.shape)
+    assert rel_l2(cpu64(xd.grad), dx) < 1e-4
+
+
+def test_bias_gradients_survive_the_next_forward(net):
+    """Gradient accumulation over two micro-batches with torch's own accumulation (the drop-in Model under
+    torch.optim): the conv-bias gradients of the first backward must not alias memory that the second forward
+    clears.  Eval-mode BatchNorm makes those gradients non-zero."""
+    mod, _ = net
+    g = O.build_graph("ntu-rgb+d", "spatial")
+    sd = O.det_state(3, 60, g["A"], True, dtype=torch.float32)
+    m = mod.Model(3, 60, dict(layout="ntu-rgb+d", strategy="spatial"), True).to(DEV)
+    m.load_state_dict(sd, strict=True)
+    xs = [O.det_input(2, 3, 24, 25, 2, tag=3500 + i).float().to(DEV) for i in range(2)]
+    labels = torch.tensor([1, 2], device=DEV)
+    m.train()
+    for bn in [mm for mm in m.modules() if isinstance(mm, torch.nn.modules.batchnorm._BatchNorm)]:
+        bn.eval()                                           # fine-tuning with frozen statistics
+    singles = []
+    for x in xs:
+        m.zero_grad(set_to_none=True)
+        torch.nn.functional.cross_entropy(m(x), labels).backward()
+        singles.append({k: p.grad.detach().clone() for k, p in m.named_parameters()})
+    m.zero_grad(set_to_none=True)
+    for x in xs:
+        torch.nn.functional.cross_entropy(m(x), labels).backward()
+    for k, p in m.named_parameters():
+        if k.endswith("tcn.2.bias") or k.endswith("residual.0.bias"):
+            want = singles[0][k] + singles[1][k]
+            assert want.abs().max() > 0
+            assert float((p.grad - want).abs().max() / want.abs().max()) < 1e-5, k

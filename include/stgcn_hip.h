@@ -29,6 +29,9 @@ extern "C" {
 #define STGCN_BF16 1
 #define STGCN_EPI_PLAIN 0    /* out = acc + bias;                   stats += [sum out, sum out^2]        */
 #define STGCN_EPI_RELU_BWD 1 /* out = (ep_scale*aux+ep_shift>0)?acc:0; stats += [sum out, sum out*xhat(aux)] */
+#define STGCN_EPI_ADD_RELU 2 /* out = max(acc + bias + aux, 0), aux optional, no statistics: the whole output stage of
+                              * an st_gcn block in eval mode (net/st_gcn.py:169, 193-197) once BatchNorm is folded
+                              * into the conv weights and bias; aux = the residual branch */
 
 /* Convolution along T as an implicit GEMM (MFMA):
  *   out[b,to,v,co] = bias[co] + sum_tap sum_ci pro(in[b, ti, v, ci]) * w[tap][co][ci]

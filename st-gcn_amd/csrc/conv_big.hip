@@ -319,9 +319,9 @@ __global__ __launch_bounds__(WR * WC * 64) void conv_big_kernel(ConvBigArgs a) {
                         else { const int t = u / V; rr = (a.os * t + a.opar) * V + (u - t * V); }
                     }
                     rrow[i] = rr;
-                    if constexpr (EPI == 1) {
+                    if constexpr (EPI != 0) {
                         av[i] = zero16();
-                        if (rr >= 0) av[i] = *(const i32x4*)(auxb + (size_t)rr * Cout);
+                        if (rr >= 0 && a.aux) av[i] = *(const i32x4*)(auxb + (size_t)rr * Cout);
                     }
                 }
 #pragma unroll
@@ -340,6 +340,12 @@ __global__ __launch_bounds__(WR * WC * 64) void conv_big_kernel(ConvBigArgs a) {
                                 s1[j] += f[j];
                                 s2[j] = fmaf(f[j], y[j], s2[j]);        // raw moment; centred once at the end of the kernel
                             }
+                            v = pack16<T>(f);
+                        } else if constexpr (EPI == 2) {          // + residual, ReLU (BatchNorm folded into weights and bias)
+                            float y[VEC];
+                            unpack16<T>(av[i], y);
+#pragma unroll
+                            for (int j = 0; j < VEC; ++j) f[j] = fmaxf(f[j] + y[j], 0.f);
                             v = pack16<T>(f);
                         } else {
 #pragma unroll
@@ -421,14 +427,14 @@ static int conv_big_launch_any(ConvBigArgs& a, int epi, hipStream_t stream, bool
     // epilogue staging rows are twice as wide
     const bool narrow = a.Cout <= 64 || !ET<T>::IS_BF16;
     if (fit256 && (waste256 <= waste128 + 0.10 || !fit128)) {
-        if (narrow) return epi == 1 ? launch_conv_big<T, 8, 1, 1, 2, 1>(a, stream) : launch_conv_big<T, 8, 1, 1, 2, 0>(a, stream);
+        if (narrow) return epi == 1 ? launch_conv_big<T, 8, 1, 1, 2, 1>(a, stream) : epi == 2 ? launch_conv_big<T, 8, 1, 1, 2, 2>(a, stream) : launch_conv_big<T, 8, 1, 1, 2, 0>(a, stream);
         if constexpr (ET<T>::IS_BF16)
-            return epi == 1 ? launch_conv_big<T, 4, 2, 2, 2, 1>(a, stream) : launch_conv_big<T, 4, 2, 2, 2, 0>(a, stream);
+            return epi == 1 ? launch_conv_big<T, 4, 2, 2, 2, 1>(a, stream) : epi == 2 ? launch_conv_big<T, 4, 2, 2, 2, 2>(a, stream) : launch_conv_big<T, 4, 2, 2, 2, 0>(a, stream);
     }
     if (fit128) {
-        if (narrow) return epi == 1 ? launch_conv_big<T, 4, 1, 1, 2, 1>(a, stream) : launch_conv_big<T, 4, 1, 1, 2, 0>(a, stream);
+        if (narrow) return epi == 1 ? launch_conv_big<T, 4, 1, 1, 2, 1>(a, stream) : epi == 2 ? launch_conv_big<T, 4, 1, 1, 2, 2>(a, stream) : launch_conv_big<T, 4, 1, 1, 2, 0>(a, stream);
         if constexpr (ET<T>::IS_BF16)
-            return epi == 1 ? launch_conv_big<T, 4, 2, 1, 2, 1>(a, stream) : launch_conv_big<T, 4, 2, 1, 2, 0>(a, stream);
+            return epi == 1 ? launch_conv_big<T, 4, 2, 1, 2, 1>(a, stream) : epi == 2 ? launch_conv_big<T, 4, 2, 1, 2, 2>(a, stream) : launch_conv_big<T, 4, 2, 1, 2, 0>(a, stream);
     }
     return -1;
 }

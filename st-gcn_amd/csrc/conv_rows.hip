@@ -27,6 +27,7 @@ struct ConvRowsArgs {
 
 #define EPI_PLAIN 0      // out = acc + bias ; stats = sum(out), sum(out^2)
 #define EPI_RELU_BWD 1   // out = (ep_scale*aux+ep_shift > 0) ? acc : 0 ; stats = sum(out), sum(out*xhat(aux))
+#define EPI_ADD_RELU 2   // out = max(acc + bias + aux, 0) (aux optional): the block's output stage when BatchNorm is folded away
 
 constexpr int CR_RS = 144;   // LDS row stride: 128 data bytes + 16 pad (conflict-free ds_read_b128)
 
@@ -211,6 +212,9 @@ __global__ __launch_bounds__(256) void conv_rows_kernel(ConvRowsArgs a) {
                         val = (fmaf(y, e_sc, e_sh) > 0.f) ? val : 0.f;
                         s1 += val;
                         s2 += val * ((y - e_mu) * e_rs);
+                    } else if constexpr (EPI == EPI_ADD_RELU) {
+                        if (a.aux) val += load_elem<T>((const T*)a.aux, o);
+                        val = fmaxf(val, 0.f);
                     } else {
                         s1 += val;
                         s2 += val * val;
@@ -263,6 +267,7 @@ static int conv_rows_dispatch(ConvRowsArgs& a, int epi, hipStream_t stream) {
         if (!a.aux || !a.ep_scale || !a.ep_shift || !a.ep_mean || !a.ep_rstd) return STGCN_ERR_ARG;
         return launch_conv_rows<T, 1, 2, EPI_RELU_BWD>(a, stream);
     }
+    if (epi == EPI_ADD_RELU) return launch_conv_rows<T, 1, 2, EPI_ADD_RELU>(a, stream);
     return launch_conv_rows<T, 1, 2, EPI_PLAIN>(a, stream);
 }
 
@@ -293,13 +298,13 @@ extern "C" int stgcn_conv_rows(int dtype, const void* in, const void* w_packed, 
     if (!in || !w_packed || !out) return STGCN_ERR_ARG;
     if ((pro_scale == nullptr) != (pro_shift == nullptr)) return STGCN_ERR_ARG;
     if (dtype == STGCN_BF16 && stride == 1 && dil == 1 && ntaps >= 1 && pad == (ntaps - 1) / 2 && Tin == Tout && B > 0 && Tin > 0 &&
-        (epilogue == EPI_PLAIN || (aux && ep_scale && ep_shift && ep_mean && ep_rstd))) {
+        (epilogue == EPI_PLAIN || epilogue == EPI_ADD_RELU || (aux && ep_scale && ep_shift && ep_mean && ep_rstd))) {
         const int rc = conv_t9_try(in, w_packed, out, bias, pro_scale, pro_shift, epilogue, aux, ep_scale, ep_shift, ep_mean, ep_rstd,
                                    stats, B, Tin, V, Cin, Cout, ntaps, transposed, (hipStream_t)stream);
         if (rc >= 0) return rc;
     }
     if ((dtype == STGCN_BF16 || dtype == STGCN_F32) && B > 0 && Tin > 0 && Tout > 0 &&
-        (epilogue == EPI_PLAIN || (epilogue == EPI_RELU_BWD && aux && ep_scale && ep_shift && ep_mean && ep_rstd))) {
+        (epilogue == EPI_PLAIN || epilogue == EPI_ADD_RELU || (epilogue == EPI_RELU_BWD && aux && ep_scale && ep_shift && ep_mean && ep_rstd))) {
         const int rc = conv_big_try(dtype, in, w_packed, out, bias, pro_scale, pro_shift, epilogue, aux, ep_scale, ep_shift, ep_mean, ep_rstd,
                                     stats, B, Tin, Tout, V, Cin, Cout, ntaps, stride, pad, dil, transposed, (hipStream_t)stream);
         if (rc >= 0) return rc;

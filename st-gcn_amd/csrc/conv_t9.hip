@@ -65,7 +65,7 @@ __global__ __launch_bounds__(T9_NT) void conv_t9_kernel(ConvT9Args a) {
 
     const uint16_t* inb = (const uint16_t*)a.in + (size_t)b * R * Cin;
     uint16_t* outb = (uint16_t*)a.out + (size_t)b * R * Cout;
-    const uint16_t* auxb = (EPI == 1) ? (const uint16_t*)a.aux + (size_t)b * R * Cout : nullptr;
+    const uint16_t* auxb = (EPI != 0 && a.aux) ? (const uint16_t*)a.aux + (size_t)b * R * Cout : nullptr;
 
     // staging / epilogue role: fixed 8-channel group per thread
     const int sseg = tid & 7, srow = tid >> 3;
@@ -148,12 +148,12 @@ __global__ __launch_bounds__(T9_NT) void conv_t9_kernel(ConvT9Args a) {
         const int pnew = p0 + T9_BM + half * V;          // first row the NEXT tile adds to the window
         if (more) fetch_rows(pnew);                       // in flight during the MFMA phase
         i32x4 av[NPF];                                    // auxiliary rows of this tile, fetched ahead of their use
-        if constexpr (EPI == 1) {
+        if constexpr (EPI != 0) {
 #pragma unroll
             for (int i = 0; i < NPF; ++i) {
                 const int row = p0 + srow + SROWS * i;
                 av[i] = zero16();
-                if (row < R && cok) av[i] = *(const i32x4*)(auxb + (size_t)row * Cout + co0 + sseg * 8);
+                if (row < R && cok && auxb) av[i] = *(const i32x4*)(auxb + (size_t)row * Cout + co0 + sseg * 8);
             }
         }
 
@@ -235,6 +235,12 @@ __global__ __launch_bounds__(T9_NT) void conv_t9_kernel(ConvT9Args a) {
                         s2[j] = fmaf(f[j], y[j], s2[j]);        // raw moment; centred once at the end of the kernel
                     }
                     v = pack16<bf16>(f);
+                } else if constexpr (EPI == 2) {                  // + residual, ReLU (BatchNorm folded into weights and bias)
+                    float y[8];
+                    unpack16<bf16>(av[i], y);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) f[j] = fmaxf(f[j] + y[j], 0.f);
+                    v = pack16<bf16>(f);
                 } else {
 #pragma unroll
                     for (int j = 0; j < 8; ++j) { s1[j] += f[j]; s2[j] += f[j] * f[j]; }
@@ -303,5 +309,5 @@ int conv_t9_try(const void* in, const void* w, void* out, const float* bias, con
     a.aux = aux; a.ep_scale = ep_scale; a.ep_shift = ep_shift; a.ep_mean = ep_mean; a.ep_rstd = ep_rstd; a.stats = stats;
     a.B = B; a.R = T * V; a.V = V; a.Cout = Cout; a.ntaps = ntaps; a.transposed = transposed;
     a.tiles_per_seg = 0; a.segs_per_sample = 0;
-    return epilogue == 1 ? launch_conv_t9<1>(a, stream) : launch_conv_t9<0>(a, stream);
+    return epilogue == 1 ? launch_conv_t9<1>(a, stream) : epilogue == 2 ? launch_conv_t9<2>(a, stream) : launch_conv_t9<0>(a, stream);
 }

@@ -55,6 +55,7 @@ class Model(nn.Module):
 
         self.fcn = nn.Conv2d(256, num_class, kernel_size=1)
         self._packer = None
+        self._plan = None                               # (key, folded inference parameters): see _eval_plan
 
     def _pack_specs(self, dtype):
         specs = []
@@ -79,7 +80,86 @@ class Model(nn.Module):
             out.append((pk.get(blk.gcn.conv.weight), pk.get(blk.tcn[2].weight), res))
         return out
 
+    # ---- inference path: BatchNorm folded away -------------------------------------------------------------------
+    # In eval mode every BatchNorm is an affine map with fixed coefficients and Dropout is the identity, so a block is
+    #   y = gcn(x);  h = relu(s1 * y + t1);  out = relu(conv(h; s2 * W) + (s2 * b + t2) + res)
+    # (net/st_gcn.py:159-171, 191-197 of the reference with model.eval(), as processor/recognition.py:110-143 and
+    # Model.extract_feature run it): s2 and the residual BatchNorm's scale go into the convolution weights, the shifts
+    # into the biases, and the add + ReLU into the temporal convolution's epilogue.  Two or three launches per block,
+    # none for statistics; the folded parameters are rebuilt only when a parameter or running statistic has changed.
+    @staticmethod
+    def _affine(bn):
+        s = bn.weight.detach().float() * torch.rsqrt(bn.running_var.float() + bn.eps)
+        return s.contiguous(), (bn.bias.detach().float() - bn.running_mean.float() * s).contiguous()
+
+    def _eval_plan(self, dtype, device):
+        tensors = list(self.parameters()) + list(self.buffers())
+        key = (dtype, device, tuple((t.data_ptr(), t._version) for t in tensors))
+        if self._plan is not None and self._plan[0] == key:
+            return self._plan[1]
+        with torch.no_grad():
+            plan = {"data_bn": self._affine(self.data_bn), "blocks": []}
+            for i, blk in enumerate(self.st_gcn_networks):
+                K = blk.gcn.kernel_size
+                cin_p = P.pad_to(blk.in_channels, P.kstep(dtype))
+                imp = self.edge_importance[i]
+                A = (self.A * imp).float().contiguous() if isinstance(imp, torch.Tensor) else (self.A * float(imp)).float().contiguous()
+                s1, t1 = self._affine(blk.tcn[0])
+                s2, t2 = self._affine(blk.tcn[3])
+                conv = blk.tcn[2]
+                ent = dict(A=A, wg=P.pack_gcn_w(blk.gcn.conv.weight.detach(), K, cin_p, dtype),
+                           bg=blk.gcn.conv.bias.detach().float().contiguous(), s1=s1, t1=t1,
+                           w2=P.pack_conv_w(conv.weight.detach().float() * s2[:, None, None, None], dtype),
+                           b2=(conv.bias.detach().float() * s2 + t2).contiguous(), wr=None, br=None)
+                if blk.residual_kind == "conv":
+                    sr, tr = self._affine(blk.residual[1])
+                    rc = blk.residual[0]
+                    ent["wr"] = P.pack_conv_w(rc.weight.detach().float() * sr[:, None, None, None], dtype)
+                    ent["br"] = (rc.bias.detach().float() * sr + tr).contiguous()
+                plan["blocks"].append(ent)
+        self._plan = (key, plan)
+        return plan
+
+    def _foldable(self):
+        """Inference with nothing to differentiate and every BatchNorm / Dropout in eval mode."""
+        if torch.is_grad_enabled() or self.data_bn.training:
+            return False
+        return not any(b.tcn[0].training or b.tcn[3].training or (b.tcn[4].training and b.tcn[4].p > 0) or
+                       (b.residual_kind == "conv" and b.residual[1].training) for b in self.st_gcn_networks)
+
+    def _trunk_folded(self, x, pool_last):
+        from stgcn_rt import lib as L
+        N, C, T, V, M = x.size()
+        dtype = self.compute_dtype
+        P.check_device(x, "input")
+        x = x.float().contiguous()
+        plan = self._eval_plan(dtype, x.device)
+        cp = P.pad_to(C, P.kstep(dtype))
+        sd, td = plan["data_bn"]
+        h = P.new_act(N * M, cp, T, V, dtype, x.device)
+        L.call("stgcn_data_bn_apply", L.dtype_code(dtype), L.ptr(x), L.ptr(h), L.ptr(sd), L.ptr(td), N, C, T, V, M, cp, L.stream_ptr())
+        for blk, e in zip(self.st_gcn_networks, plan["blocks"]):
+            Cout, stride = blk.out_channels, blk.stride
+            kt = blk.tcn[2].kernel_size[0]
+            Tin = h.shape[2]
+            To = (Tin - 1) // stride + 1
+            y = P.gcn_fused(h, e["wg"], e["A"], Cout, bias=e["bg"], adj_t=True)
+            if blk.residual_kind == "conv":
+                res = P.conv_rows(h, e["wr"], Cout, To, bias=e["br"], ntaps=1, stride=stride, pad=0)
+            else:
+                res = h if blk.residual_kind == "identity" else None
+            h = P.conv_rows(y, e["w2"], Cout, To, bias=e["b2"], pro=(e["s1"], e["t1"]), epilogue=L.EPI_ADD_RELU, aux=res,
+                            ntaps=kt, stride=stride, pad=(kt - 1) // 2)
+        if pool_last:
+            B, Cc, To, _ = h.shape
+            pooled = torch.empty((B, Cc), dtype=torch.float32, device=h.device)
+            L.call("stgcn_pool_fwd", L.dtype_code(dtype), L.ptr(h), L.ptr(pooled), B, To * V, Cc, L.stream_ptr())
+            return pooled
+        return h
+
     def _trunk(self, x, pool_last=False):
+        if self._foldable():
+            return self._trunk_folded(x, pool_last)
         N, C, T, V, M = x.size()
         dtype = self.compute_dtype
         bn = self.data_bn

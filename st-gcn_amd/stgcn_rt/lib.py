@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libstgcn_hip.so")
 
 F32, BF16 = 0, 1
-EPI_PLAIN, EPI_RELU_BWD = 0, 1
+EPI_PLAIN, EPI_RELU_BWD, EPI_ADD_RELU = 0, 1, 2
 
 _lib = None
 

@@ -102,6 +102,34 @@ def test_conv_rows_forward(rt, case, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("with_res", [True, False], ids=["res", "nores"])
+@pytest.mark.parametrize("case", [CONV_CASES[0], CONV_CASES[1], CONV_CASES[5], CONV_CASES[7], CONV_CASES[8], CONV_CASES[10], CONV_CASES[12]],
+                         ids=lambda c: "x".join(map(str, c)))
+def test_conv_rows_add_relu_epilogue(rt, case, with_res, dtype):
+    """out = relu(conv(relu(scale * x + shift)) + bias + residual): the output stage of an eval-mode block with its
+    BatchNorms folded into weights and bias, in each of the three convolution kernels (LDS ring, tiled, generic)."""
+    from stgcn_rt import lib as L
+    B, Cin, Cout, T, V, kt, stride, pad, pro = case
+    x = q(t64((B, Cin, T, V), 41), dtype)
+    W = q(t64((Cout, Cin, kt), 42) * (1.5 / np.sqrt(Cin * kt)), dtype)
+    b = t64((Cout,), 43, -0.2, 0.2)
+    sc, sh = t64((Cin,), 44, 0.5, 1.5), t64((Cin,), 45, -0.3, 0.3)
+    h = torch.clamp_min(x * sc[None, :, None, None] + sh[None, :, None, None], 0) if pro else x
+    if pro and dtype == torch.bfloat16:
+        h = q(h, dtype)
+    o = O.tconv_forward(h, W, b, stride, pad)
+    res = q(t64(tuple(o.shape), 46), dtype) if with_res else None
+    ref = torch.clamp_min(o + (res if with_res else 0), 0)
+    wp = rt.pack_conv_w(W[..., None].to(DEV).float(), dtype)
+    out = rt.conv_rows(to_dev(x, dtype), wp, Cout, o.shape[2], bias=b.to(DEV).float(),
+                       pro=(sc.to(DEV).float(), sh.to(DEV).float()) if pro else None, epilogue=L.EPI_ADD_RELU,
+                       aux=to_dev(res, dtype) if with_res else None, ntaps=kt, stride=stride, pad=pad)
+    torch.cuda.synchronize()
+    assert out.shape == ref.shape and float(out.min()) >= 0
+    assert rel(out, ref) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
 # the transposed form contracts over Cout: whole 128-byte chunks only
 @pytest.mark.parametrize("case", [c for c in CONV_CASES[:4] + CONV_CASES[6:] if c[2] % 64 == 0], ids=lambda c: "x".join(map(str, c)))
 def test_conv_rows_transposed_and_wgrad(rt, case, dtype):

@@ -628,3 +628,49 @@ def test_bias_gradients_survive_the_next_forward(net):
             want = singles[0][k] + singles[1][k]
             assert want.abs().max() > 0
             assert float((p.grad - want).abs().max() / want.abs().max()) < 1e-5, k
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("ci", [i for i, c in enumerate(C.MODEL_CASES) if not c[6]], ids=[c[0] for c in C.MODEL_CASES if not c[6]])
+def test_folded_inference_path(net, golden, ci, dtype):
+    """Inference under torch.no_grad() takes the path with BatchNorm folded into the convolution weights and the
+    add + ReLU fused into the temporal convolution (2-3 launches per block): logits against the reference's golden
+    eval vectors for every layout / partition strategy, extract_feature against its fixtures, and the folded
+    parameters must follow an in-place change of a running statistic."""
+    mod, _ = net
+    from stgcn_rt import ops as P
+    name, lay, ncls, N, T, M, _ = C.MODEL_CASES[ci]
+    strat = C.strategy_of(name)
+    g = O.build_graph(lay, strat)
+    sd = O.det_state(3, ncls, g["A"], True, dtype=torch.float32)
+    x, _ = C.model_inputs(ci)
+    m = mod.Model(3, ncls, dict(layout=lay, strategy=strat), True, compute_dtype=dtype).to(DEV)
+    m.load_state_dict(sd, strict=True)
+    m.eval()
+    xd = x.float().to(DEV)
+    tol = TOL[dtype]
+    P.TIMING, P.TIMING_NAMES = {}, None
+    with torch.no_grad():
+        assert m._foldable()
+        logits = m(xd)
+    launches = sum(v[0] for v in P.timing_summary().values())
+    P.TIMING = None
+    assert launches <= 10 * 2 + 2, launches                  # gcn + conv per block, + the two 1x1 residual convolutions
+    assert rel(cpu64(logits), golden["model"][name + "/logits"]) < tol
+    general = m(xd)                                           # grad enabled: the general path (separate BatchNorm stages)
+    assert not m._foldable() and rel(cpu64(logits), cpu64(general)) < tol
+    if name.endswith("small_eval"):
+        with torch.no_grad():
+            out, feat = m.extract_feature(xd)
+        assert rel(cpu64(out), golden["model"][name + "/feat_output"]) < tol
+        assert rel(cpu64(feat), golden["model"][name + "/feat_feature"]) < tol
+    # a running statistic changes in place: the next forward must re-fold
+    with torch.no_grad():
+        m.st_gcn_networks[2].tcn[3].running_var.mul_(1.7)
+        m.st_gcn_networks[4].residual[1].running_mean.add_(0.05)
+        after = m(xd)
+    sd2 = {k: (v.double().clone() if v.is_floating_point() else v) for k, v in sd.items()}
+    sd2["st_gcn_networks.2.tcn.3.running_var"] *= 1.7
+    sd2["st_gcn_networks.4.residual.1.running_mean"] += 0.05
+    lo, _, _ = O.model_forward(sd2, x, False)
+    assert rel(cpu64(after), lo) < tol and rel(cpu64(after), cpu64(logits)) > 1e-4

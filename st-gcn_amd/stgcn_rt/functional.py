@@ -5,6 +5,8 @@
   DataBnFn      Model.forward input normalisation    (net/st_gcn.py:72-78)
   HeadFn        pooling + fcn                        (net/st_gcn.py:85-90)
 """
+import os
+
 import torch
 
 from . import lib as L
@@ -15,6 +17,44 @@ from . import ops as P
 # (inner ReLU after BN1, final ReLU) so a checker can evaluate its reference with the same decisions.
 CAPTURE = None
 CAPTURE_TENSORS = False
+
+# Parameter-gradient kernels of a block's backward (conv_wgrad, gcn_wgrad, gcn_agrad) are off the chain that carries the
+# data gradient to the previous block.  With OVERLAP_WGRAD they are launched on a second stream: they fork from the
+# current stream once their inputs exist and are joined before the block's backward returns, so the MFMA-bound
+# weight-gradient kernels run beside the chain's HBM-bound elementwise kernels (BatchNorm backward, block output
+# backward of the next block's tensors) instead of in front of them.  Every tensor they read outlives the join.
+OVERLAP_WGRAD = os.environ.get("STGCN_OVERLAP_WGRAD", "1") == "1"
+_SIDE = {}
+
+
+def _side_stream(dev):
+    s = _SIDE.get(dev.index)
+    if s is None:
+        s = _SIDE[dev.index] = torch.cuda.Stream(device=dev)
+    return s
+
+
+class _Fork:
+    """`with _Fork(side, ev):` runs its body on `side` after the event `ev` of the current stream (no-op when side is
+    None).  The event is recorded where the body's inputs are complete; the body is ISSUED later, behind the chain's
+    next MFMA kernel, so that the device starts that one first and the body runs beside what follows it.  The caller
+    joins with `torch.cuda.current_stream().wait_stream(side)`."""
+
+    def __init__(self, side, ev):
+        self.side = side
+        self.ev = ev
+        self.ctx = None
+
+    def __enter__(self):
+        if self.side is not None:
+            self.side.wait_event(self.ev)
+            self.ctx = torch.cuda.stream(self.side)
+            self.ctx.__enter__()
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            self.ctx.__exit__(*exc)
+        return False
 
 
 def _act_dtype(dtype):
@@ -179,8 +219,10 @@ class StGcnBlockFn(torch.autograd.Function):
 
         # temporal conv: weight grad (input = relu(bn1(y)) recomputed in the prologue), then data grad fused with
         # the ReLU mask and the BN1-backward sums
-        dWt = P.conv_wgrad(y, dO, kt, stride, pad, pro=(bn1.scale, bn1.shift))
+        side = _side_stream(dev) if OVERLAP_WGRAD else None
         stats1 = P.stats_alloc((2 * Cout,), dev)
+        dWr = None
+        ev = torch.cuda.current_stream().record_event() if side is not None else None
         gh = P.conv_rows(dO, packs[1][1], Cout, T, epilogue=L.EPI_RELU_BWD, aux=y, ep=(bn1.scale, bn1.shift, bn1.mean, bn1.rstd),
                          stats=stats1, ntaps=kt, stride=stride, pad=pad, transposed=True)
         if CAPTURE is not None:
@@ -191,23 +233,28 @@ class StGcnBlockFn(torch.autograd.Function):
             if CAPTURE_TENSORS:                  # diagnostics (tools/grad_budget.py): what each kernel read and wrote
                 CAPTURE[-1].update(x=x, y=y, o=o, r=r_, dout=dout, dpool=dpool, dO=dO, dR=dR, g=g, gh=gh.clone(),
                                    bn=(bn1, bn2, bnr), relu_mask=ctx.relu_mask)
+        with _Fork(side, ev):                            # issued behind the data-gradient kernel: runs beside bn_bwd_apply
+            dWt = P.conv_wgrad(y, dO, kt, stride, pad, pro=(bn1.scale, bn1.shift))
+            if kind == "conv":
+                dWr = P.conv_wgrad(x, dR, 1, stride, 0)
         dy, dg1, db1 = P.bn_bwd_apply(gh, y, f32(g1), bn1, stats1, training, out=gh, want_grads=True)
+        ev = torch.cuda.current_stream().record_event() if side is not None else None
 
         add = g
-        dWr = None
         if kind == "conv":
-            dWr = P.conv_wgrad(x, dR, 1, stride, 0)
             add = P.conv_rows(dR, packs[2][1], cin_p, T, ntaps=1, stride=stride, pad=0, transposed=True)
-
         if mask_in_dx:
             dx = P.gcn_fused(dy, packs[0][1], A32, cin_p, add=dout, add_mask=ctx.relu_mask)
         else:
             dx = P.gcn_fused(dy, packs[0][1], A32, cin_p, add=add)
-        dWp, dbg = P.gcn_wgrad(x, dy, A32, need_bias=True)
-        dWg = dWp[:, :, :cin_true].reshape(Wg.shape)
         dA = None
-        if ctx.needs_input_grad[1]:
-            dA = P.gcn_agrad(x, packs[0][0], f32(bg), dy)
+        with _Fork(side, ev):
+            dWp, dbg = P.gcn_wgrad(x, dy, A32, need_bias=True)
+            dWg = dWp[:, :, :cin_true].reshape(Wg.shape)
+            if ctx.needs_input_grad[1]:
+                dA = P.gcn_agrad(x, packs[0][0], f32(bg), dy)
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)
         if CAPTURE is not None and CAPTURE_TENSORS:
             CAPTURE[-1].update(dy=dy, dx=dx, dA=dA, add=add)
         return (dx, dA, dWg, dbg, dg1, db1, dWt, dbt, dg2, db2, dWr, dbr_f, dgr, dbetar,

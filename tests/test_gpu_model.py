@@ -631,6 +631,44 @@ def test_bias_gradients_survive_the_next_forward(net):
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+def test_weight_gradients_on_the_side_stream(net, dtype):
+    """A block's backward launches its parameter-gradient kernels on a second stream, beside the data-gradient chain,
+    and joins before it returns: every gradient equals the single-stream run's, at a batch whose kernels are long enough to overlap and
+    over several backward passes in a row (a stale or early read would show as a large difference)."""
+    mod, _ = net
+    import stgcn_rt.functional as F
+    g = O.build_graph("ntu-rgb+d", "spatial")
+    sd = O.det_state(3, 60, g["A"], True, dtype=torch.float32)
+    x = O.det_input(8, 3, 64, 25, 2, tag=3700).float().to(DEV)
+    labels = torch.arange(8, device=DEV) * 7 % 60
+    m = mod.Model(3, 60, dict(layout="ntu-rgb+d", strategy="spatial"), True, dropout=0.0, compute_dtype=dtype).to(DEV)
+    m.load_state_dict(sd, strict=True)
+    m.train()
+    assert F.OVERLAP_WGRAD, "the side stream is the default"
+    runs = {True: [], False: []}
+    try:
+        for overlap in (True, False, True):
+            F.OVERLAP_WGRAD = overlap
+            for rep in range(3):
+                m.zero_grad(set_to_none=True)
+                torch.nn.functional.cross_entropy(m(x), labels).backward()
+            torch.cuda.synchronize()
+            runs[overlap].append({k: p.grad.detach().double().cpu() for k, p in m.named_parameters()})
+    finally:
+        F.OVERLAP_WGRAD = True
+    # Two identical float32 runs differ by up to 4e-3 in single small tensors (the forward's BatchNorm sums are
+    # atomics: last-bit differences move ReLU decisions of elements at zero); bf16 storage absorbs those bits and
+    # repeats to 1e-7.  So bf16 is the sharp check, float32 is bounded per tensor and over the whole gradient vector.
+    ref = runs[False][0]
+    keys = [k for k in ref if not (k.endswith("tcn.2.bias") or k.endswith("residual.0.bias") or k.endswith("gcn.conv.bias"))]
+    for got in runs[True]:
+        for k in keys:                                     # the skipped biases are cancelled by the BatchNorm behind them
+            assert rel_l2(got[k], ref[k]) < (5e-2 if dtype == torch.float32 else 1e-5), k
+        whole = rel_l2(torch.cat([got[k].reshape(-1) for k in keys]), torch.cat([ref[k].reshape(-1) for k in keys]))
+        assert whole < (2e-3 if dtype == torch.float32 else 1e-6), whole
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
 @pytest.mark.parametrize("ci", [i for i, c in enumerate(C.MODEL_CASES) if not c[6]], ids=[c[0] for c in C.MODEL_CASES if not c[6]])
 def test_folded_inference_path(net, golden, ci, dtype):
     """Inference under torch.no_grad() takes the path with BatchNorm folded into the convolution weights and the

@@ -334,6 +334,34 @@ def tconv_backward(h, W, do, stride=1, pad=None, dil=1, need_bias=True):
 
 
 # --------------------------------------------------------------------------
+# Graph convolution with a temporal kernel  (net/utils/tgcn.py:44-66: Conv2d((t_kernel_size,1), stride, padding,
+# dilation) to K*Cout channels, then the einsum over the K partitions)
+# --------------------------------------------------------------------------
+
+def gcn_temporal_forward(x, A, W, b, stride=1, pad=0, dil=1):
+    """y[b,c,t',w] = sum_k sum_v z[b,kC+c,t',v] A[k,v,w],  z = tconv_forward(x, W, b).  W [K*Cout, Cin, kt]."""
+    K = A.shape[0]
+    z = tconv_forward(x, W, b, stride, pad, dil)            # [B, K*Cout, T', V]
+    Cout = z.shape[1] // K
+    y = None
+    for k in range(K):
+        t = torch.matmul(z[:, k * Cout:(k + 1) * Cout], A[k])
+        y = t if y is None else y + t
+    return y.contiguous()
+
+
+def gcn_temporal_backward(x, A, W, b, dy, stride=1, pad=0, dil=1):
+    """Returns dx, dW, db, dA for gcn_temporal_forward."""
+    K = A.shape[0]
+    z = tconv_forward(x, W, b, stride, pad, dil)
+    Cout = z.shape[1] // K
+    dz = torch.cat([torch.matmul(dy, A[k].t()) for k in range(K)], dim=1)       # [B, K*Cout, T', V]
+    dA = torch.stack([torch.tensordot(z[:, k * Cout:(k + 1) * Cout], dy, dims=([0, 1, 2], [0, 1, 2])) for k in range(K)])
+    dx, dW, db = tconv_backward(x, W, dz, stride, pad, dil, need_bias=b is not None)
+    return dx, dW, db, dA
+
+
+# --------------------------------------------------------------------------
 # BatchNorm over all axes but dim 1 (torch defaults: eps 1e-5, momentum 0.1)
 # --------------------------------------------------------------------------
 

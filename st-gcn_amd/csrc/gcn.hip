@@ -388,7 +388,8 @@ struct GcnAgradArgs {
 // NA as in gcn_fused_kernel.  Each wave keeps the K 32x32 partial dA tiles in accumulators over all its frames;
 // the waves' tiles are summed through LDS at the end and the workgroup writes one partial to the slab.  NWV (waves
 // per workgroup) as in gcn_fused_kernel.
-template <typename T, int NA, int NWV>
+// RAG: Cout is not a multiple of 32 (the last column tile is ragged).
+template <typename T, int NA, int NWV, bool RAG>
 __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : 2) void gcn_agrad_kernel(GcnAgradArgs a) {
     constexpr int NTHR = NWV * 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -456,8 +457,18 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : 2) void gcn_agrad_kernel(G
         for (int nt = 0; nt < 4; ++nt) {
             if (nt < NTW && cbase + nt * 32 < Cout) {
 #pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    dyr[nt][g] = *(const dyraw_t*)(dyp + (size_t)(cbase + nt * 32 + 8 * g + 4 * h) * ES);
+                for (int g = 0; g < 4; ++g) {
+                    const int c = cbase + nt * 32 + 8 * g + 4 * h;
+                    if constexpr (RAG) {
+                        // Cout is a multiple of 8, not of 32: the last tile's channels past Cout meet zero weight
+                        // rows, but must not be read -- past the last row they lie outside the tensor
+                        dyraw_t v = {};
+                        if (c < Cout) v = *(const dyraw_t*)(dyp + (size_t)c * ES);
+                        dyr[nt][g] = v;
+                    } else {
+                        dyr[nt][g] = *(const dyraw_t*)(dyp + (size_t)c * ES);
+                    }
+                }
             }
         }
 #pragma unroll
@@ -598,13 +609,18 @@ __global__ __launch_bounds__(256) void sum_parts_wave_kernel(const float* slab, 
     if (lane == 0) out[i] = s;
 }
 
-template <typename T, int NA, int NWV>
-static int gcn_agrad_launch2(GcnAgradArgs& a, dim3 grid, size_t lds, hipStream_t stream) {
-    auto kern = gcn_agrad_kernel<T, NA, NWV>;
+template <typename T, int NA, int NWV, bool RAG>
+static int gcn_agrad_launch3(GcnAgradArgs& a, dim3 grid, size_t lds, hipStream_t stream) {
+    auto kern = gcn_agrad_kernel<T, NA, NWV, RAG>;
     static std::atomic<uint64_t> lds_ok{0};
     if (stgcn_allow_big_lds((const void*)kern, lds_ok) != STGCN_OK) return STGCN_ERR_LAUNCH;
     hipLaunchKernelGGL(kern, grid, dim3(NWV * 64), lds, stream, a);
     return hipGetLastError() == hipSuccess ? STGCN_OK : STGCN_ERR_LAUNCH;
+}
+template <typename T, int NA, int NWV>
+static int gcn_agrad_launch2(GcnAgradArgs& a, dim3 grid, size_t lds, hipStream_t stream) {
+    if (a.Cout % 32 != 0) return gcn_agrad_launch3<T, NA, NWV, true>(a, grid, lds, stream);
+    return gcn_agrad_launch3<T, NA, NWV, false>(a, grid, lds, stream);
 }
 template <typename T, int NA>
 static int gcn_agrad_launch(GcnAgradArgs& a, dim3 grid, size_t lds, int nwv, hipStream_t stream) {

@@ -124,6 +124,51 @@ class GraphConvFn(torch.autograd.Function):
         return dx, dA, dW, db, None
 
 
+class TemporalConvFn(torch.autograd.Function):
+    """Conv2d with a (kt, 1) kernel, stride, zero padding and dilation along T (the projection of
+    ConvTemporalGraphical when t_kernel_size > 1, net/utils/tgcn.py:48-60).  x [B, cin_p, T, V] channel-padded to
+    whole 128-byte chunks; returns [B, cout_p, T', V] with the output channels padded the same way (the padding is
+    zero and the caller keeps it: the next kernel contracts over it)."""
+
+    @staticmethod
+    def forward(ctx, x, W, b, cfg, cin_true):
+        P.check_act(x)
+        kt, stride, pad, dil = cfg
+        x = P.cl(x)
+        dtype = x.dtype
+        B, cin_p, T, V = x.shape
+        Cout = W.shape[0]
+        cout_p = P.pad_to(Cout, P.kchunk(dtype))         # the input gradient contracts over whole chunks of these
+        To = (T + 2 * pad - dil * (kt - 1) - 1) // stride + 1
+        if To < 1:
+            raise ValueError("temporal kernel longer than the padded clip: T=%d, kernel %d, dilation %d, padding %d" % (T, kt, dil, pad))
+        Wp = torch.zeros((cout_p, cin_p, kt, 1), dtype=torch.float32, device=x.device)
+        Wp[:Cout, :W.shape[1]] = W.detach().float()
+        bias = torch.zeros((cout_p,), dtype=torch.float32, device=x.device)
+        if b is not None:
+            bias[:Cout] = b.detach().float()
+        z = P.conv_rows(x, P.pack_conv_w(Wp, dtype), cout_p, To, bias=bias, ntaps=kt, stride=stride, pad=pad, dil=dil)
+        ctx.save_for_backward(x, Wp)
+        ctx.cfg = (kt, stride, pad, dil, Cout, cin_true, b is not None, tuple(W.shape))
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        x, Wp = ctx.saved_tensors
+        kt, stride, pad, dil, Cout, cin_true, has_bias, wshape = ctx.cfg
+        dtype = x.dtype
+        B, cin_p, T, V = x.shape
+        dz = P.cl(dz.to(dtype))
+        dx = dW = db = None
+        if ctx.needs_input_grad[0]:
+            dx = P.conv_rows(dz, P.pack_conv_wt(Wp, dtype), cin_p, T, ntaps=kt, stride=stride, pad=pad, dil=dil, transposed=True)
+        if ctx.needs_input_grad[1]:
+            dW = P.conv_wgrad(x, dz, kt, stride, pad, dil)[:Cout, :cin_true].reshape(wshape)
+        if has_bias and ctx.needs_input_grad[2]:
+            db = dz[:, :Cout].float().sum(dim=(0, 2, 3))
+        return dx, dW, db, None, None
+
+
 class StGcnBlockFn(torch.autograd.Function):
     """One st_gcn block.  Positional tensors:
        x, A, Wg, bg, g1, b1, Wt, bt, g2, b2, Wr, br, gr, betar  (the last four None unless conv residual)

@@ -28,6 +28,14 @@ GCN_CASES = [
     ("ntu_spatial_64_128_t10", "ntu-rgb+d", "spatial", True, 1, 64, 128, 10),
 ]
 
+# ConvTemporalGraphical with a temporal kernel: (name, layout, strategy, B, Cin, Cout, T, t_kernel, t_stride, t_pad, t_dil)
+GCN_T_CASES = [
+    ("ntu_spatial_8_16_t20_k3", "ntu-rgb+d", "spatial", 2, 8, 16, 20, 3, 1, 1, 1),
+    ("kin_uniform_3_8_t21_k3_s2_d2", "openpose", "uniform", 2, 3, 8, 21, 3, 2, 2, 2),
+    ("ntu_distance_16_24_t19_k5_p0", "ntu-rgb+d", "distance", 1, 16, 24, 19, 5, 1, 0, 1),
+    ("ntu_spatial_64_32_t16_k9_s3", "ntu-rgb+d", "spatial", 1, 64, 32, 16, 9, 3, 4, 1),
+]
+
 # (name, layout, cin, cout, stride, residual, B, T, training)
 BLOCK_CASES = [
     ("ntu_none_3_64_s1_train", "ntu-rgb+d", 3, 64, 1, False, 2, 20, True),
@@ -130,6 +138,19 @@ def gcn_inputs(case, tag0):
     W = O.det_uniform((K * Cout, Cin), tag0 + 3) * (1.5 / np.sqrt(Cin))
     b = O.det_uniform((K * Cout,), tag0 + 4, -0.2, 0.2)
     dy = O.det_uniform((B, Cout, T, V), tag0 + 5)
+    return t64(x), t64(A), t64(W), t64(b), t64(dy)
+
+
+def gcn_t_inputs(case, tag0):
+    name, lay, strat, B, Cin, Cout, T, kt, stride, pad, dil = case
+    A0 = O.build_graph(lay, strat)["A"]
+    K, V = A0.shape[0], A0.shape[1]
+    A = A0 * O.det_uniform(A0.shape, tag0 + 1, 0.5, 1.5)
+    x = O.det_uniform((B, Cin, T, V), tag0 + 2)
+    W = O.det_uniform((K * Cout, Cin, kt), tag0 + 3) * (1.5 / np.sqrt(Cin * kt))
+    b = O.det_uniform((K * Cout,), tag0 + 4, -0.2, 0.2)
+    To = O.tconv_out_len(T, kt, stride, pad, dil)
+    dy = O.det_uniform((B, Cout, To, V), tag0 + 5)
     return t64(x), t64(A), t64(W), t64(b), t64(dy)
 
 

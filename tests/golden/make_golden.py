@@ -28,7 +28,7 @@ from net.utils.tgcn import ConvTemporalGraphical as RefGCN  # noqa: E402
 
 torch.set_default_dtype(torch.float64)
 
-from tests.golden.cases import (GRAPH_CASES, GCN_CASES, BLOCK_CASES, MODEL_CASES, FEEDER_CASES, t64, compact,  # noqa: E402
+from tests.golden.cases import (GRAPH_CASES, GCN_CASES, GCN_T_CASES, gcn_t_inputs, BLOCK_CASES, MODEL_CASES, FEEDER_CASES, t64, compact,  # noqa: E402
                                 gcn_inputs, block_inputs, model_inputs, feeder_clip, strategy_of)
 
 
@@ -69,6 +69,32 @@ def gen_gcn():
             out[name + "/" + k] = compact(ref[k])
     np.savez_compressed(os.path.join(HERE, "gcn_op.npz"), **out)
     print("gcn op: %d cases, oracle <1e-12" % len(GCN_CASES))
+
+
+def gen_gcn_temporal():
+    """ConvTemporalGraphical with t_kernel_size > 1, strides, padding and dilation (net/utils/tgcn.py:44-66)."""
+    out = {}
+    for ci, case in enumerate(GCN_T_CASES):
+        name, lay, strat, B, Cin, Cout, T, kt, stride, pad, dil = case
+        x, A, W, b, dy = gcn_t_inputs(case, 7000 + 10 * ci)
+        K = A.shape[0]
+        m = RefGCN(Cin, Cout, K, t_kernel_size=kt, t_stride=stride, t_padding=pad, t_dilation=dil).double()
+        with torch.no_grad():
+            m.conv.weight.copy_(W.reshape(m.conv.weight.shape))
+            m.conv.bias.copy_(b)
+        xr = x.clone().requires_grad_(True)
+        Ar = A.clone().requires_grad_(True)
+        y, _ = m(xr, Ar)
+        y.backward(dy)
+        ref = dict(y=y.detach(), dx=xr.grad, dW=m.conv.weight.grad.reshape(W.shape), db=m.conv.bias.grad, dA=Ar.grad)
+        my = O.gcn_temporal_forward(x, A, W, b, stride, pad, dil)
+        mdx, mdW, mdb, mdA = O.gcn_temporal_backward(x, A, W, b, dy, stride, pad, dil)
+        for k, v in dict(y=my, dx=mdx, dW=mdW, db=mdb, dA=mdA).items():
+            err = (v - ref[k]).abs().max().item() / (ref[k].abs().max().item() + 1e-30)
+            assert err < 1e-12, (name, k, err)
+            out[name + "/" + k] = compact(ref[k])
+    np.savez_compressed(os.path.join(HERE, "gcn_temporal.npz"), **out)
+    print("gcn with temporal kernel: %d cases, oracle <1e-12" % len(GCN_T_CASES))
 
 
 def gen_block():
@@ -227,12 +253,13 @@ if __name__ == "__main__":
     torch.set_num_threads(8)
     if len(sys.argv) > 1:                      # e.g. `make_golden.py feeder model`: regenerate only those files
         for what in sys.argv[1:]:
-            {"graph": gen_graphs, "gcn": gen_gcn, "block": gen_block, "model": gen_model, "sgd": gen_sgd,
+            {"graph": gen_graphs, "gcn": gen_gcn, "gcn_temporal": gen_gcn_temporal, "block": gen_block, "model": gen_model, "sgd": gen_sgd,
              "feeder": gen_feeder}[what]()
         sys.exit(0)
     gen_feeder()
     gen_graphs()
     gen_gcn()
+    gen_gcn_temporal()
     gen_block()
     gen_model()
     gen_sgd()

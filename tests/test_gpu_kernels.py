@@ -243,6 +243,78 @@ def test_gcn_kernels(rt, case, dtype):
     assert rel(dAk, dA) < tol
 
 
+def fenced(t, cl=False):
+    """The same device tensor with NaN on both sides of its memory: a read past either end -- even one that only meets
+    zero weights -- turns the output into NaN.  cl: a [B,C,T,V] activation in channels-last layout."""
+    src = t.permute(0, 2, 3, 1).contiguous() if cl else t.contiguous()
+    n, pad = src.numel(), 4096
+    buf = torch.full((n + 2 * pad,), float("nan"), dtype=t.dtype, device=t.device)
+    buf[pad:pad + n] = src.reshape(-1)
+    v = buf[pad:pad + n].view(src.shape)
+    return v.permute(0, 3, 1, 2) if cl else v
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("lay,strat,B,Cin,Cout,T", [("openpose", "uniform", 1, 16, 8, 5), ("ntu-rgb+d", "spatial", 2, 48, 24, 3),
+                                                    ("ntu-rgb+d", "spatial", 1, 32, 80, 4), ("openpose", "distance", 1, 256, 40, 2)])
+def test_gcn_kernels_stay_inside_their_inputs(rt, lay, strat, B, Cin, Cout, T, dtype):
+    """Channel counts that are multiples of one k-step but not of a 32-column tile, every input fenced with NaN:
+    results finite and equal to the oracle's (a ragged tile's spare columns meet zero weights -- they must not be read)."""
+    if dtype == torch.bfloat16 and Cout % 16:
+        Cout += 8                                # the gradient kernels contract over whole k-steps of Cout (16 in bf16)
+    A0 = O.build_graph(lay, strat)["A"]
+    K, V = A0.shape[0], A0.shape[1]
+    A = torch.tensor(A0) * t64(A0.shape, 61, 0.5, 1.5)
+    x = q(t64((B, Cin, T, V), 62), dtype)
+    W = q(t64((K * Cout, Cin), 63) * (1.5 / np.sqrt(Cin)), dtype)
+    b = t64((K * Cout,), 64, -0.2, 0.2)
+    dy = q(t64((B, Cout, T, V), 65), dtype)
+    Aq = q(A, dtype)
+    y = O.gcn_forward(x, Aq, W, b)
+    dx, dW, db, dA = O.gcn_backward(x, Aq, W, b, dy)
+    Ad = fenced(A.to(DEV).float())
+    W4 = W.reshape(K * Cout, Cin, 1, 1).to(DEV).float()
+    bd = fenced(b.to(DEV).float())
+    xd, dyd = fenced(to_dev(x, dtype), cl=True), fenced(to_dev(dy, dtype), cl=True)
+    assert xd.is_contiguous(memory_format=torch.channels_last)
+    wp, wt = fenced(rt.pack_gcn_w(W4, K, Cin, dtype)), fenced(rt.pack_gcn_wt(W4, K, Cin, dtype))
+    tol = TOL[dtype]
+    stats = torch.zeros(2 * Cout, dtype=torch.float64, device=DEV)
+    got = dict(y=(rt.gcn_fused(xd, wp, Ad, Cout, bias=bd, stats=stats, adj_t=True), y),
+               dx=(rt.gcn_fused(dyd, wt, Ad, Cin), dx))
+    dWk, dbk = rt.gcn_wgrad(xd, dyd, Ad)
+    got.update(dW=(dWk.reshape(K * Cout, Cin), dW), db=(dbk, db), dA=(rt.gcn_agrad(xd, wp, bd, dyd), dA),
+               dA_nobias=(rt.gcn_agrad(xd, wp, None, dyd), O.gcn_backward(x, Aq, W, None, dy)[3]))
+    for k, (g, want) in got.items():
+        assert bool(torch.isfinite(g).all()), k
+        assert rel(g, want) < tol, k
+    assert bool(torch.isfinite(stats).all())
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("case", [(1, 64, 8, 7, 18, 3, 1, 1, 1), (2, 64, 24, 9, 25, 9, 2, 4, 1), (1, 128, 40, 6, 25, 1, 1, 0, 1),
+                                  (1, 64, 64, 11, 18, 3, 2, 2, 2), (2, 64, 64, 10, 25, 5, 3, 0, 1)], ids=lambda c: "x".join(map(str, c)))
+def test_conv_kernels_stay_inside_their_inputs(rt, case, dtype):
+    """The temporal convolution at narrow / ragged output widths, strides up to 3 and dilation, inputs fenced with NaN."""
+    B, Cin, Cout, T, V, kt, stride, pad, dil = case
+    x = q(t64((B, Cin, T, V), 71), dtype)
+    W = q(t64((Cout, Cin, kt), 72) * (1.5 / np.sqrt(Cin * kt)), dtype)
+    b = t64((Cout,), 73, -0.2, 0.2)
+    ref = O.tconv_forward(x, W, b, stride, pad, dil)
+    To = ref.shape[2]
+    do = q(t64((B, Cout, To, V), 74), dtype)
+    dh, dW, _ = O.tconv_backward(x, W, do, stride, pad, dil)
+    xd, dod = fenced(to_dev(x, dtype), cl=True), fenced(to_dev(do, dtype), cl=True)
+    W4 = W[..., None].to(DEV).float()
+    out = rt.conv_rows(xd, fenced(rt.pack_conv_w(W4, dtype)), Cout, To, bias=fenced(b.to(DEV).float()), ntaps=kt, stride=stride, pad=pad, dil=dil)
+    assert bool(torch.isfinite(out).all()) and rel(out, ref) < TOL[dtype]
+    gW = rt.conv_wgrad(xd, dod, kt, stride, pad, dil)
+    assert bool(torch.isfinite(gW).all()) and rel(gW[..., 0], dW) < TOL[dtype]
+    if Cout % 64 == 0:                       # the transposed form contracts over Cout: whole 128-byte chunks only
+        got = rt.conv_rows(dod, fenced(rt.pack_conv_wt(W4, dtype)), Cin, T, ntaps=kt, stride=stride, pad=pad, dil=dil, transposed=True)
+        assert bool(torch.isfinite(got).all()) and rel(got, dh) < TOL[dtype]
+
+
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
 @pytest.mark.parametrize("Cc,rows_shape", [(64, (2, 20, 25)), (128, (1, 19, 18)), (256, (2, 5, 25)), (96, (1, 7, 25)), (64, (3, 300, 25)),
                                             (64, (128, 300, 25))])       # the benchmarked step's largest activation: 960 000 rows

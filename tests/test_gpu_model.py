@@ -93,6 +93,33 @@ def test_conv_temporal_graphical(net, golden, ci, dtype):
         assert rel(C.compact(cpu64(v)), G[name + "/" + k]) < tol, (k, rel(C.compact(cpu64(v)), G[name + "/" + k]))
 
 
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("ci", range(len(C.GCN_T_CASES)), ids=[c[0] for c in C.GCN_T_CASES])
+def test_conv_temporal_graphical_with_temporal_kernel(net, golden, ci, dtype):
+    """t_kernel_size > 1 with stride, padding and dilation (net/utils/tgcn.py:44-66) against the reference's own
+    outputs and gradients."""
+    _, tg = net
+    case = C.GCN_T_CASES[ci]
+    name, lay, strat, B, Cin, Cout, T, kt, stride, pad, dil = case
+    x, A, W, b, dy = C.gcn_t_inputs(case, 7000 + 10 * ci)
+    K = A.shape[0]
+    m = tg.ConvTemporalGraphical(Cin, Cout, K, t_kernel_size=kt, t_stride=stride, t_padding=pad, t_dilation=dil).to(DEV)
+    assert tuple(m.conv.weight.shape) == (K * Cout, Cin, kt, 1)
+    with torch.no_grad():
+        m.conv.weight.copy_(W.reshape(m.conv.weight.shape))
+        m.conv.bias.copy_(b)
+    xr = x.to(DEV).to(dtype).requires_grad_(True)
+    Ar = A.to(DEV).float().requires_grad_(True)
+    y, A_out = m(xr, Ar)
+    assert A_out is Ar and tuple(y.shape) == tuple(dy.shape)
+    y.backward(dy.to(DEV).to(dtype))
+    G = golden["gcn_temporal"]
+    tol = TOL[dtype]
+    got = dict(y=y, dx=xr.grad, dW=m.conv.weight.grad.reshape(W.shape), db=m.conv.bias.grad, dA=Ar.grad)
+    for k, v in got.items():
+        assert rel(C.compact(cpu64(v)), G[name + "/" + k]) < tol, (k, rel(C.compact(cpu64(v)), G[name + "/" + k]))
+
+
 def test_conv_temporal_graphical_contract(net):
     _, tg = net
     m = tg.ConvTemporalGraphical(8, 16, 3).to(DEV)

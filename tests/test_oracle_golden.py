@@ -44,6 +44,18 @@ def test_gcn_op(golden, ci):
         assert rel(C.compact(v), golden["gcn_op"][case[0] + "/" + k]) < TOL, k
 
 
+@pytest.mark.parametrize("ci", range(len(C.GCN_T_CASES)), ids=[c[0] for c in C.GCN_T_CASES])
+def test_gcn_with_temporal_kernel(golden, ci):
+    """ConvTemporalGraphical with t_kernel_size > 1, stride, padding, dilation (net/utils/tgcn.py:44-66)."""
+    case = C.GCN_T_CASES[ci]
+    stride, pad, dil = case[8], case[9], case[10]
+    x, A, W, b, dy = C.gcn_t_inputs(case, 7000 + 10 * ci)
+    y = O.gcn_temporal_forward(x, A, W, b, stride, pad, dil)
+    dx, dW, db, dA = O.gcn_temporal_backward(x, A, W, b, dy, stride, pad, dil)
+    for k, v in dict(y=y, dx=dx, dW=dW, db=db, dA=dA).items():
+        assert rel(C.compact(v), golden["gcn_temporal"][case[0] + "/" + k]) < TOL, k
+
+
 @pytest.mark.parametrize("ci", range(len(C.BLOCK_CASES)), ids=[c[0] for c in C.BLOCK_CASES])
 def test_block(golden, ci):
     case = C.BLOCK_CASES[ci]

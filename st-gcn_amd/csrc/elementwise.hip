@@ -526,29 +526,57 @@ extern "C" int stgcn_bn_bwd_apply(int dtype, const void* g, const void* y, void*
 // ------------------------------------------------------------------------------------------
 // data_bn: BatchNorm1d over channel index v*C + c of x[N, C, T, V, M] (f32), statistics over
 // (n, m, t); output is the channels-last [N*M][T][V][Cp] activation (Cp >= C, padding zero).
+// FIXED: thread (r, j) = (tid / VM, tid % VM) keeps position j = v*M + m of the contiguous [t][v][m] slab and walks
+// frames t0 + r, t0 + r + R, ...; the partial sums are folded over r and m in a fixed order, so a workgroup's sums do
+// not depend on how its waves were scheduled (float atomics in LDS, the other form, add in arrival order: the
+// statistics, and with them every activation of a float32 forward pass, then change in their last bits from run to
+// run).  Needs V*M <= 256.
+template <bool FIXED>
 __global__ __launch_bounds__(256) void data_bn_stats_kernel(const float* x, double* stats, int N, int C, int T, int V, int M) {
-    // one workgroup per (n, c, t-chunk); thread j walks the contiguous [t][v][m] slab
-    extern __shared__ float sh[];               // [2][V]
+    // one workgroup per (n, c, t-chunk)
+    extern __shared__ float sh[];               // FIXED: [2][R][VM], else [2][V]
     const int nc = blockIdx.x;                  // n*C + c
     const int c = nc % C;
     const int VM = V * M;
-    for (int i = threadIdx.x; i < 2 * V; i += blockDim.x) sh[i] = 0.f;
-    __syncthreads();
     const int tchunk = (T + gridDim.y - 1) / gridDim.y;
     const int t0 = blockIdx.y * tchunk, t1 = min(T, t0 + tchunk);
     const float* base = x + (size_t)nc * T * VM;
-    // each thread keeps one (v) if VM divides the stride pattern; general: atomics in LDS
-    for (int i = t0 * VM + threadIdx.x; i < t1 * VM; i += blockDim.x) {
-        const float val = base[i];
-        const int v = (i % VM) / M;
-        atomicAdd(&sh[v], val);
-        atomicAdd(&sh[V + v], val * val);
-    }
-    __syncthreads();
     const int VC = V * C;
-    for (int v = threadIdx.x; v < V; v += blockDim.x) {
-        atomicAdd(&stats[v * C + c], (double)sh[v]);
-        atomicAdd(&stats[VC + v * C + c], (double)sh[V + v]);
+    if constexpr (FIXED) {
+        const int R = 256 / VM;
+        const int r = threadIdx.x / VM, j = threadIdx.x - r * VM;
+        if (r < R) {
+            float s = 0.f, s2 = 0.f;
+            for (int t = t0 + r; t < t1; t += R) {
+                const float val = base[(size_t)t * VM + j];
+                s += val;
+                s2 = fmaf(val, val, s2);
+            }
+            sh[r * VM + j] = s;
+            sh[(R + r) * VM + j] = s2;
+        }
+        __syncthreads();
+        for (int v = threadIdx.x; v < V; v += blockDim.x) {
+            float s = 0.f, s2 = 0.f;
+            for (int rr = 0; rr < R; ++rr)
+                for (int m = 0; m < M; ++m) { s += sh[rr * VM + v * M + m]; s2 += sh[(R + rr) * VM + v * M + m]; }
+            atomicAdd(&stats[v * C + c], (double)s);
+            atomicAdd(&stats[VC + v * C + c], (double)s2);
+        }
+    } else {
+        for (int i = threadIdx.x; i < 2 * V; i += blockDim.x) sh[i] = 0.f;
+        __syncthreads();
+        for (int i = t0 * VM + threadIdx.x; i < t1 * VM; i += blockDim.x) {
+            const float val = base[i];
+            const int v = (i % VM) / M;
+            atomicAdd(&sh[v], val);
+            atomicAdd(&sh[V + v], val * val);
+        }
+        __syncthreads();
+        for (int v = threadIdx.x; v < V; v += blockDim.x) {
+            atomicAdd(&stats[v * C + c], (double)sh[v]);
+            atomicAdd(&stats[VC + v * C + c], (double)sh[V + v]);
+        }
     }
 }
 
@@ -574,30 +602,57 @@ __global__ __launch_bounds__(256) void data_bn_apply_kernel(const float* x, T* o
     }
 }
 
-template <typename T>
+// FIXED (V*C <= 256): thread (r, ch) keeps channel ch = v*C + c and walks frames t0 + r, t0 + r + R, ...; fixed-order
+// fold over r.  Otherwise float atomics in LDS (arrival order).
+template <typename T, bool FIXED>
 __global__ __launch_bounds__(256) void data_bn_bwd_kernel(const T* dx0, const float* x, const float* mean, const float* rstd,
                                                          double* stats, int N, int C, int T_, int V, int M, int Cp) {
-    // one workgroup per (n*M+m, t-chunk): accumulate dbeta/dgamma per (v, c) in LDS, then double atomics
-    extern __shared__ float sh[];               // [2][V*C]
+    // one workgroup per (n*M+m, t-chunk): dbeta/dgamma per (v, c) in LDS, then double atomics
+    extern __shared__ float sh[];               // FIXED: [2][R][VC], else [2][VC]
     const int VC = V * C;
-    for (int i = threadIdx.x; i < 2 * VC; i += blockDim.x) sh[i] = 0.f;
-    __syncthreads();
     const int b = blockIdx.x;
     const int n = b / M, mm = b % M;
     const int tchunk = (T_ + gridDim.y - 1) / gridDim.y;
     const int t0 = blockIdx.y * tchunk, t1 = min(T_, t0 + tchunk);
-    for (int i = t0 * VC + threadIdx.x; i < t1 * VC; i += blockDim.x) {
-        const int c = i % C;
-        const int v = (i / C) % V;
-        const int t = i / VC;
-        const float d = load_elem<T>(dx0, (((size_t)b * T_ + t) * V + v) * Cp + c);
-        const float xv = x[((((size_t)n * C + c) * T_ + t) * V + v) * M + mm];
-        const int ch = v * C + c;
-        atomicAdd(&sh[ch], d);
-        atomicAdd(&sh[VC + ch], d * ((xv - mean[ch]) * rstd[ch]));
+    if constexpr (FIXED) {
+        const int R = 256 / VC;
+        const int r = threadIdx.x / VC, ch = threadIdx.x - r * VC;
+        if (r < R) {
+            const int v = ch / C, c = ch - v * C;
+            const float mu = mean[ch], rs = rstd[ch];
+            float s = 0.f, s2 = 0.f;
+            for (int t = t0 + r; t < t1; t += R) {
+                const float d = load_elem<T>(dx0, (((size_t)b * T_ + t) * V + v) * Cp + c);
+                const float xv = x[((((size_t)n * C + c) * T_ + t) * V + v) * M + mm];
+                s += d;
+                s2 = fmaf(d, (xv - mu) * rs, s2);
+            }
+            sh[r * VC + ch] = s;
+            sh[(R + r) * VC + ch] = s2;
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < 2 * VC; i += blockDim.x) {
+            const int which = i / VC, ch = i - which * VC;
+            float s = 0.f;
+            for (int rr = 0; rr < R; ++rr) s += sh[(which * R + rr) * VC + ch];
+            atomicAdd(&stats[i], (double)s);
+        }
+    } else {
+        for (int i = threadIdx.x; i < 2 * VC; i += blockDim.x) sh[i] = 0.f;
+        __syncthreads();
+        for (int i = t0 * VC + threadIdx.x; i < t1 * VC; i += blockDim.x) {
+            const int c = i % C;
+            const int v = (i / C) % V;
+            const int t = i / VC;
+            const float d = load_elem<T>(dx0, (((size_t)b * T_ + t) * V + v) * Cp + c);
+            const float xv = x[((((size_t)n * C + c) * T_ + t) * V + v) * M + mm];
+            const int ch = v * C + c;
+            atomicAdd(&sh[ch], d);
+            atomicAdd(&sh[VC + ch], d * ((xv - mean[ch]) * rstd[ch]));
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < 2 * VC; i += blockDim.x) atomicAdd(&stats[i], (double)sh[i]);
     }
-    __syncthreads();
-    for (int i = threadIdx.x; i < 2 * VC; i += blockDim.x) atomicAdd(&stats[i], (double)sh[i]);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -643,7 +698,11 @@ extern "C" int stgcn_augment(const float* in, float* out, const int* shift, cons
 extern "C" int stgcn_data_bn_stats(const float* x, double* stats, int N, int C, int T, int V, int M, void* stream) {
     if (!x || !stats || N < 1 || C < 1 || T < 1 || V < 1 || M < 1) return STGCN_ERR_ARG;
     int gy = (T + 31) / 32; if (gy > 16) gy = 16;
-    hipLaunchKernelGGL(data_bn_stats_kernel, dim3((unsigned)(N * C), (unsigned)gy), dim3(256), 2 * V * sizeof(float), (hipStream_t)stream, x, stats, N, C, T, V, M);
+    const dim3 grid((unsigned)(N * C), (unsigned)gy);
+    if (V * M <= 256)
+        hipLaunchKernelGGL(data_bn_stats_kernel<true>, grid, dim3(256), 2 * (size_t)(256 / (V * M)) * V * M * sizeof(float), (hipStream_t)stream, x, stats, N, C, T, V, M);
+    else
+        hipLaunchKernelGGL(data_bn_stats_kernel<false>, grid, dim3(256), 2 * (size_t)V * sizeof(float), (hipStream_t)stream, x, stats, N, C, T, V, M);
     return hipGetLastError() == hipSuccess ? STGCN_OK : STGCN_ERR_LAUNCH;
 }
 extern "C" int stgcn_data_bn_apply(int dtype, const float* x, void* out, const float* scale, const float* shift,
@@ -660,12 +719,18 @@ extern "C" int stgcn_data_bn_bwd(int dtype, const void* dx0, const float* x, con
                                  int N, int C, int T, int V, int M, int Cp, void* stream) {
     if (!dx0 || !x || !mean || !rstd || !stats || Cp < C) return STGCN_ERR_ARG;
     int gy = (T + 31) / 32; if (gy > 16) gy = 16;
-    const size_t lds = 2 * (size_t)V * C * sizeof(float);
+    const bool fixed = V * C <= 256;
+    const size_t lds = 2 * (size_t)(fixed ? 256 / (V * C) : 1) * V * C * sizeof(float);
     if (lds > 64 * 1024) return STGCN_ERR_ARG;
     dim3 grid((unsigned)(N * M), (unsigned)gy);
-    if (dtype == STGCN_BF16) hipLaunchKernelGGL(data_bn_bwd_kernel<bf16>, grid, dim3(256), lds, (hipStream_t)stream, (const bf16*)dx0, x, mean, rstd, stats, N, C, T, V, M, Cp);
-    else if (dtype == STGCN_F32) hipLaunchKernelGGL(data_bn_bwd_kernel<float>, grid, dim3(256), lds, (hipStream_t)stream, (const float*)dx0, x, mean, rstd, stats, N, C, T, V, M, Cp);
-    else return STGCN_ERR_ARG;
+    if (dtype != STGCN_BF16 && dtype != STGCN_F32) return STGCN_ERR_ARG;
+    if (dtype == STGCN_BF16) {
+        if (fixed) hipLaunchKernelGGL((data_bn_bwd_kernel<bf16, true>), grid, dim3(256), lds, (hipStream_t)stream, (const bf16*)dx0, x, mean, rstd, stats, N, C, T, V, M, Cp);
+        else hipLaunchKernelGGL((data_bn_bwd_kernel<bf16, false>), grid, dim3(256), lds, (hipStream_t)stream, (const bf16*)dx0, x, mean, rstd, stats, N, C, T, V, M, Cp);
+    } else {
+        if (fixed) hipLaunchKernelGGL((data_bn_bwd_kernel<float, true>), grid, dim3(256), lds, (hipStream_t)stream, (const float*)dx0, x, mean, rstd, stats, N, C, T, V, M, Cp);
+        else hipLaunchKernelGGL((data_bn_bwd_kernel<float, false>), grid, dim3(256), lds, (hipStream_t)stream, (const float*)dx0, x, mean, rstd, stats, N, C, T, V, M, Cp);
+    }
     return hipGetLastError() == hipSuccess ? STGCN_OK : STGCN_ERR_LAUNCH;
 }
 

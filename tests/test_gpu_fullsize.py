@@ -169,6 +169,31 @@ def test_model_full_batch_eval_is_per_clip(net, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+def test_model_full_batch_train_repeats_bit_for_bit(net, dtype):
+    """N = 64, T = 300, train mode, dropout 0.5: two runs of one batch from one state give the same logits and the same
+    parameter gradients bit for bit.  Every reduction is either fixed-order (slabs, per-thread sums folded in a fixed
+    order) or a double-precision atomic sum of float32 partials -- exact, hence order-free, unless partials of one
+    channel differ by more than 2^29 in size; the parameter-gradient kernels run on a second stream meanwhile."""
+    x = O.det_input(64, 3, 300, 25, 2, tag=4245).float().to(DEV)
+    labels = torch.tensor([(11 * i + 5) % 60 for i in range(64)], device=DEV)
+    res = []
+    for rep in range(2):
+        torch.manual_seed(77)                             # the dropout masks derive from torch's seed
+        m = _ntu_model(net, dtype, dropout=0.5).train()
+        logits = m(x)
+        torch.nn.functional.cross_entropy(logits, labels).backward()
+        torch.cuda.synchronize()
+        res.append((logits.detach().clone(), {k: p.grad.detach().clone() for k, p in m.named_parameters()},
+                    {k: b.detach().clone() for k, b in m.named_buffers()}))
+        del m, logits
+    (l0, g0, b0), (l1, g1, b1) = res
+    assert torch.equal(l0, l1)
+    differ = [k for k in g0 if not (k.endswith("tcn.2.bias") or k.endswith("residual.0.bias")) and not torch.equal(g0[k], g1[k])]
+    assert not differ, differ[:5]                         # the two skipped kinds are float32 atomic sums of exact zeros' noise
+    assert all(torch.equal(b0[k], b1[k]) for k in b0)     # running statistics
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
 def test_model_full_batch_train_is_permutation_equivariant(net, dtype):
     """N = 64, T = 300, train mode (batch statistics), dropout 0: reversing the order of the clips reverses the logits
     and leaves the parameter gradients of the mean cross-entropy where they were, up to the order of the sums."""
@@ -193,12 +218,12 @@ def test_model_full_batch_train_is_permutation_equivariant(net, dtype):
     errs.sort()
     print("relative L2 difference of the parameter gradients under permutation: median %.2e, worst %.2e (%s)"
           % (errs[len(errs) // 2][0], errs[-1][0], errs[-1][1]))
-    # What this can resolve is set by the model, not by the kernels: the batch statistics are atomic sums, so two
-    # runs of the SAME batch differ in the last bits of the forward (logits to 4e-7), and the gradients of this
-    # deep BatchNorm chain answer that with a relative change of 2-4e-3 per tensor in float32 (measured; a repeated
-    # backward on one forward is bitwise identical); in bfloat16, where a last-bit change of a statistic moves
-    # activations by 2^-9, with 7e-2 to 2e-1 from run to run -- there the per-tensor comparison says little and only
-    # the overall size of the gradient is held.  A wrong sample index or a dropped tile shows as O(1).
+    # What this can resolve is set by the model, not by the kernels: reversing the clips changes the order of every
+    # batch-statistics sum, so the forward differs in its last bits (logits to 4e-7), and the gradients of this deep
+    # BatchNorm chain answer that with a relative change of 2-4e-3 per tensor in float32 (ReLU decisions of elements
+    # at zero move); in bfloat16, where a last-bit change of a statistic moves activations by 2^-9, with 7e-2 to 2e-1
+    # -- there the per-tensor comparison says little and only the overall size of the gradient is held.  A wrong
+    # sample index or a dropped tile shows as O(1).  (The SAME batch twice is bitwise equal: the test above.)
     med, worst = errs[len(errs) // 2], errs[-1]
     if dtype == torch.float32:
         assert med[0] < 1e-2, med

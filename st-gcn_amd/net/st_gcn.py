@@ -259,6 +259,44 @@ class st_gcn(nn.Module):
     def forward(self, x, A):
         return self._run(x, A, False)[0], A
 
+    def _run_padded(self, x, A, cfg, cp, bn1, conv, bn2, rargs, rbufs, dtype):
+        """Channel widths that are no multiple of one 128-byte chunk (64 channels in bf16, 32 in float32; no reference
+        net has them): the block runs at the padded output width cp, and its input is padded to the width its residual
+        branch needs.  Every parameter is zero-padded with differentiable tensor ops, so autograd slices the gradients
+        back; a padded channel has weight 0, BatchNorm gamma 0 and beta 0 and therefore stays exactly 0 through both
+        BatchNorms, the ReLUs and the residual sum, forward and backward.  Running statistics are updated on padded
+        copies and written back."""
+        import torch.nn.functional as TF
+        K = self.gcn.kernel_size
+        cout = self.out_channels
+        d = cp - cout
+        vec = lambda t: TF.pad(t, (0, d))
+        kind = self.residual_kind
+        want = cp if kind == "identity" else (P.pad_to(self.in_channels, P.kchunk(dtype)) if kind == "conv" else x.size(1))
+        if x.size(1) != want:
+            x = P.pad_channels(x, want)
+        Wg = self.gcn.conv.weight
+        Wg_p = TF.pad(Wg.reshape(K, cout, Wg.shape[1]), (0, want - Wg.shape[1], 0, d)).reshape(K * cp, want, 1, 1)
+        bg_p = TF.pad(self.gcn.conv.bias.reshape(K, cout), (0, d)).reshape(-1) if self.gcn.conv.bias is not None else None
+        Wt_p = TF.pad(conv.weight, (0, 0, 0, 0, 0, d, 0, d))
+        rargs_p = rargs
+        if kind == "conv":
+            Wr, br, gr, betar = rargs
+            rargs_p = (TF.pad(Wr, (0, 0, 0, 0, 0, want - Wr.shape[1], 0, d)), vec(br), vec(gr), vec(betar))
+        mean_p = lambda t: None if t is None else TF.pad(t.detach(), (0, d))
+        var_p = lambda t: None if t is None else TF.pad(t.detach(), (0, d), value=1.0)
+        bufs = [bn1.running_mean, bn1.running_var, bn2.running_mean, bn2.running_var, rbufs[0], rbufs[1]]
+        bufs_p = [mean_p(bufs[0]), var_p(bufs[1]), mean_p(bufs[2]), var_p(bufs[3]), mean_p(bufs[4]), var_p(bufs[5])]
+        cfg = cfg[:5] + (want,) + cfg[6:]                               # the width the graph-conv weight gradient keeps
+        y, pooled = StGcnBlockFn.apply(x, A, Wg_p, bg_p, vec(bn1.weight), vec(bn1.bias), Wt_p, vec(conv.bias),
+                                       vec(bn2.weight), vec(bn2.bias), *rargs_p, *bufs_p, cfg, None)
+        if cfg[2]:                                                      # training: the kernels updated the padded copies
+            with torch.no_grad():
+                for dst, src in zip(bufs, bufs_p):
+                    if dst is not None:
+                        dst.copy_(src[:cout])
+        return y[:, :cout], (None if pooled is None else pooled[:, :cout])
+
     def forward_pooled(self, x, A):
         """-> (y, mean of y over (T, V) as float32 [B, C])."""
         return self._run(x, A, True)
@@ -293,9 +331,14 @@ class st_gcn(nn.Module):
                 self._drop_step = torch.zeros((), dtype=torch.int64, device=x.device)
             drop_step = own_step = self._drop_step
         cfg = (self.stride, self.residual_kind, bn_train, drop_p, (self._seed(), drop_step), cin, want_pool)
-        y, pooled = StGcnBlockFn.apply(x, A, self.gcn.conv.weight, self.gcn.conv.bias, bn1.weight, bn1.bias,
-                               conv.weight, conv.bias, bn2.weight, bn2.bias, *rargs,
-                               bn1.running_mean, bn1.running_var, bn2.running_mean, bn2.running_var, *rbufs, cfg, packs)
+        cout = self.out_channels
+        cout_p = P.pad_to(cout, P.kchunk(dtype))
+        if cout_p != cout or (self.residual_kind == "conv" and cin % P.kchunk(dtype) != 0):
+            y, pooled = self._run_padded(x, A, cfg, cout_p, bn1, conv, bn2, rargs, rbufs, dtype)
+        else:
+            y, pooled = StGcnBlockFn.apply(x, A, self.gcn.conv.weight, self.gcn.conv.bias, bn1.weight, bn1.bias,
+                                           conv.weight, conv.bias, bn2.weight, bn2.bias, *rargs,
+                                           bn1.running_mean, bn1.running_var, bn2.running_mean, bn2.running_var, *rbufs, cfg, packs)
         tracked = [b.num_batches_tracked for b in bns] if bn_train else []
         if own_step is not None:
             tracked.append(own_step)

@@ -45,6 +45,10 @@ BLOCK_CASES = [
     ("kin_id_64_64_s1_eval", "openpose", 64, 64, 1, True, 2, 20, False),
     ("kin_conv_128_256_s2_oddT_eval", "openpose", 128, 256, 2, True, 1, 19, False),
     ("kin_id_128_128_s1_train", "openpose", 128, 128, 1, True, 1, 24, True),
+    # widths that are no multiple of a 128-byte chunk of channels (the module pads them)
+    ("ntu_id_40_40_s1_train", "ntu-rgb+d", 40, 40, 1, True, 2, 14, True),
+    ("ntu_conv_24_72_s2_train", "ntu-rgb+d", 24, 72, 2, True, 2, 15, True),
+    ("kin_none_10_20_s1_eval", "openpose", 10, 20, 1, False, 1, 12, False),
 ]
 
 # (name, layout, num_class, N, T, M, training)

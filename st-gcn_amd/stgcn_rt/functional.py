@@ -19,11 +19,13 @@ CAPTURE = None
 CAPTURE_TENSORS = False
 
 # Parameter-gradient kernels of a block's backward (conv_wgrad, gcn_wgrad, gcn_agrad) are off the chain that carries the
-# data gradient to the previous block.  With OVERLAP_WGRAD they are launched on a second stream: they fork from the
-# current stream once their inputs exist and are joined before the block's backward returns, so the MFMA-bound
-# weight-gradient kernels run beside the chain's HBM-bound elementwise kernels (BatchNorm backward, block output
-# backward of the next block's tensors) instead of in front of them.  Every tensor they read outlives the join.
-OVERLAP_WGRAD = os.environ.get("STGCN_OVERLAP_WGRAD", "1") == "1"
+# data gradient to the previous block.  With OVERLAP_WGRAD (STGCN_OVERLAP_WGRAD=1) they are launched on a second
+# stream: they fork from the current stream once their inputs exist and are joined before the block's backward
+# returns, so the MFMA-bound weight-gradient kernels run beside the chain's HBM-bound elementwise kernels instead of
+# in front of them.  Every tensor they read outlives the join.  Worth 1.4-2.1 % of a training step; off by default,
+# because kernels that share the device stretch each other and per-kernel durations (profiles, the benchmark's
+# roofline record) stop describing the kernels.
+OVERLAP_WGRAD = os.environ.get("STGCN_OVERLAP_WGRAD", "0") == "1"
 _SIDE = {}
 
 

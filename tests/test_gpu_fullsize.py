@@ -173,11 +173,14 @@ def test_model_full_batch_train_repeats_bit_for_bit(net, dtype):
     """N = 64, T = 300, train mode, dropout 0.5: two runs of one batch from one state give the same logits and the same
     parameter gradients bit for bit.  Every reduction is either fixed-order (slabs, per-thread sums folded in a fixed
     order) or a double-precision atomic sum of float32 partials -- exact, hence order-free, unless partials of one
-    channel differ by more than 2^29 in size; the parameter-gradient kernels run on a second stream meanwhile."""
+    channel differ by more than 2^29 in size.  The second run has the parameter-gradient kernels on a second stream."""
+    import stgcn_rt.functional as F
     x = O.det_input(64, 3, 300, 25, 2, tag=4245).float().to(DEV)
     labels = torch.tensor([(11 * i + 5) % 60 for i in range(64)], device=DEV)
     res = []
+    was = F.OVERLAP_WGRAD
     for rep in range(2):
+        F.OVERLAP_WGRAD = rep == 1                        # second run with the weight-gradient kernels on their side stream
         torch.manual_seed(77)                             # the dropout masks derive from torch's seed
         m = _ntu_model(net, dtype, dropout=0.5).train()
         logits = m(x)
@@ -186,6 +189,7 @@ def test_model_full_batch_train_repeats_bit_for_bit(net, dtype):
         res.append((logits.detach().clone(), {k: p.grad.detach().clone() for k, p in m.named_parameters()},
                     {k: b.detach().clone() for k, b in m.named_buffers()}))
         del m, logits
+    F.OVERLAP_WGRAD = was
     (l0, g0, b0), (l1, g1, b1) = res
     assert torch.equal(l0, l1)
     differ = [k for k in g0 if not (k.endswith("tcn.2.bias") or k.endswith("residual.0.bias")) and not torch.equal(g0[k], g1[k])]

@@ -696,8 +696,8 @@ def test_data_bn_any_person_and_channel_count(net, N, Cc, T, V, M):
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
 def test_weight_gradients_on_the_side_stream(net, dtype):
-    """A block's backward launches its parameter-gradient kernels on a second stream, beside the data-gradient chain,
-    and joins before it returns: every gradient equals the single-stream run's bit for bit, at a batch whose kernels are long enough to overlap and
+    """With functional.OVERLAP_WGRAD a block's backward launches its parameter-gradient kernels on a second stream, beside
+    the data-gradient chain, and joins before it returns: every gradient equals the single-stream run's bit for bit, at a batch whose kernels are long enough to overlap and
     over several backward passes in a row (a stale or early read would show as a large difference)."""
     mod, _ = net
     import stgcn_rt.functional as F
@@ -708,7 +708,7 @@ def test_weight_gradients_on_the_side_stream(net, dtype):
     m = mod.Model(3, 60, dict(layout="ntu-rgb+d", strategy="spatial"), True, dropout=0.0, compute_dtype=dtype).to(DEV)
     m.load_state_dict(sd, strict=True)
     m.train()
-    assert F.OVERLAP_WGRAD, "the side stream is the default"
+    was = F.OVERLAP_WGRAD
     runs = {True: [], False: []}
     try:
         for overlap in (True, False, True):
@@ -719,7 +719,7 @@ def test_weight_gradients_on_the_side_stream(net, dtype):
             torch.cuda.synchronize()
             runs[overlap].append({k: p.grad.detach().double().cpu() for k, p in m.named_parameters()})
     finally:
-        F.OVERLAP_WGRAD = True
+        F.OVERLAP_WGRAD = was
     # runs of one batch repeat bit for bit (fixed-order reductions; double atomics of float32 partials are exact), so
     # any difference is the side stream's
     ref = runs[False][0]

@@ -345,8 +345,9 @@ def block_out_bwd(dout, out, o, r, bn2, gamma2, bnr, gammar, want_g, drop_p, see
     args[17], args[18], args[19] = L.ptr(dO), L.ptr(dR), L.ptr(g)
     _launch((str(o.dtype), 1, rows, Cc, has_r, want_g), "stgcn_block_out_bwd", *args)
     # the bias sums leave this function (they become .grad of the conv biases): hand out memory of their own, not
-    # views of the statistics arena, which the next training forward clears
-    dbf = dbf.clone()
+    # views of the statistics arena, which the next training forward clears (an elementwise kernel rather than
+    # clone(), which is a device-to-device memcpy: a captured step then consists of kernel nodes only)
+    dbf = dbf.mul(1.0)
     dbo, dbr = dbf[:Cc], dbf[Cc:]
     res = (dO, dR, g, stats2, (statsr if has_r else None), dbo, (dbr if has_r else None))
     if want_bn_grads:

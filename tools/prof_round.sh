@@ -12,7 +12,8 @@ cd /tmp && export TMPDIR=/tmp
 # kernel trace of the bench command (graph replay): per-kernel stats, per-step launch summary, the priced kernel's dispatches
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 $R/bench.py --no-cpu-baseline --single-dtype > $O/bench_traced.json 2> $O/kt.log || exit 1
 KS=$(ls $O/kt/*/*kernel_stats.csv | head -1); cp $KS $O/bench_bf16_kernel_stats.csv
-KT=$(ls $O/kt/*/*kernel_trace.csv | head -1); python3 $R/tools/step_trace.py $KT > $O/step_launch_summary.txt 2>&1
+KT=$(ls $O/kt/*/*kernel_trace.csv | head -1); python3 $R/tools/step_trace.py $KT 5 > $O/step_launch_summary.txt 2>&1
+python3 $R/tools/step_trace.py $KT 0 > $O/step_launch_summary_launch_by_launch.txt 2>&1
 python3 - $KT > $O/bench_bf16_dominant_kernel_dispatches.csv <<'PY'
 import csv, sys
 rows = [r for r in csv.DictReader(open(sys.argv[1])) if "conv_big_kernel<bf16, 4, 2, 2, 2, 1>" in r["Kernel_Name"]]
@@ -23,7 +24,7 @@ PY
 rm -rf $O/kt
 # the same at 8 clips per GPU: kernel busy time of a step against its wall time
 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $O/kt8 -- python3 $R/bench.py --batch 8 --no-cpu-baseline --single-dtype > $O/bench_batch8_traced.json 2> $O/kt8.log || exit 1
-python3 $R/tools/step_trace.py $(ls $O/kt8/*/*kernel_trace.csv | head -1) > $O/step_launch_summary_batch8.txt 2>&1
+python3 $R/tools/step_trace.py $(ls $O/kt8/*/*kernel_trace.csv | head -1) 5 > $O/step_launch_summary_batch8.txt 2>&1
 rm -rf $O/kt8
 # HBM traffic of the priced kernel instance: separate passes, FETCH_SIZE doubled for 16-byte-per-lane streaming reads
 timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/p1 -- python3 $R/tools/kbench.py conv_t_epi:256:256 --iters 5 > $O/p1.log 2>&1 || exit 1

@@ -120,7 +120,7 @@ int stgcn_block_out_fwd(int dtype, const void* o, const void* res, void* out, vo
 
 /* Backward of the stage above.  pass 0: per-channel sums (stats2, statsr).  pass 1: dO (BatchNorm backward of the
  * main branch), dR (same for a conv residual), g (= masked incoming gradient, for an identity residual), the
- * bias gradients of the two convolutions (dbias_*: float32 sums accumulated with atomics, zeroed by the caller) and,
+ * bias gradients of the two convolutions (dbias_*: double[C] sums accumulated with atomics, zeroed by the caller) and,
  * when asked for, the BatchNorm parameter gradients read off the sums of pass 0 (dbeta = sum, dgamma = sum*xhat).  The incoming gradient is dout and/or dpool (float32 [B][C],
  * constant over (t,v): the gradient of the global average pool).  The ReLU and dropout decisions come from relu_mask when
  * given (then out may be null), else from out and the dropout hash.
@@ -130,7 +130,7 @@ int stgcn_block_out_bwd(int dtype, int pass, const void* dout, const float* dpoo
                         const float* mean2, const float* rstd2, const float* gamma2,
                         const float* meanr, const float* rstdr, const float* gammar,
                         double* stats2, double* statsr, void* dO, void* dR, void* g,
-                        float* dbias_o, float* dbias_r,
+                        double* dbias_o, double* dbias_r,
                         float* dgamma2, float* dbeta2, float* dgammar, float* dbetar,
                         size_t rows, int C, float drop_p, uint32_t seed, double count, int training, void* stream);
 

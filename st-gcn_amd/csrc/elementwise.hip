@@ -225,7 +225,7 @@ struct BlockOutBwdArgs {
     const float* meanr; const float* rstdr; const float* gammar;
     double* stats2; double* statsr;
     void* dO; void* dR; void* g;
-    float* dbias_o; float* dbias_r;          // float32 sums (atomics), zeroed by the caller
+    double* dbias_o; double* dbias_r;        // sums (double atomics of float32 partials: order-free), zeroed by the caller
     float* dgamma2; float* dbeta2; float* dgammar; float* dbetar;   // optional: BatchNorm parameter gradients from stats2 / statsr
     size_t rows; int C; uint32_t seed, thr; float keep_scale; double count; int training;
 };
@@ -401,9 +401,9 @@ __global__ __launch_bounds__(NT) void block_out_bwd_apply_kernel(BlockOutBwdArgs
                 if (row + i * rstep < a.rows) consume(row + i * rstep, p[i]);
         }
     }
-    float* dst[2] = {a.dbias_o, HAS_R ? a.dbias_r : nullptr};
-    if constexpr (NT == 256) block_channel_reduce<T, 2, float>(sums, m, a.C, dst);
-    else wide_channel_reduce<T, HAS_R ? 2 : 1, NT, float>(sums, m, a.C, dst);
+    double* dst[2] = {a.dbias_o, HAS_R ? a.dbias_r : nullptr};
+    if constexpr (NT == 256) block_channel_reduce<T, 2>(sums, m, a.C, dst);
+    else wide_channel_reduce<T, HAS_R ? 2 : 1, NT>(sums, m, a.C, dst);
     // the sums of the reduce pass are the BatchNorm parameter gradients: dbeta = sum g, dgamma = sum g*xhat
     if (blockIdx.x == 0) {
         for (int c = threadIdx.x; c < a.C; c += NT) {
@@ -443,7 +443,7 @@ extern "C" int stgcn_block_out_bwd(int dtype, int pass, const void* dout, const 
                                    const float* mean2, const float* rstd2, const float* gamma2,
                                    const float* meanr, const float* rstdr, const float* gammar,
                                    double* stats2, double* statsr, void* dO, void* dR, void* g,
-                                   float* dbias_o, float* dbias_r,
+                                   double* dbias_o, double* dbias_r,
                                    float* dgamma2, float* dbeta2, float* dgammar, float* dbetar,
                                    size_t rows, int C, float drop_p, uint32_t seed, double count, int training, void* stream) {
     if ((!dout && !dpool) || (!out && !relu_mask) || !o || !mean2 || !rstd2 || !stats2) return STGCN_ERR_ARG;

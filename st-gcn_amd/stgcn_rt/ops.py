@@ -319,16 +319,15 @@ def block_out_fwd(o, res, bn2, bnr, drop_p, seed, want_mask=False, seed_step=Non
 
 def block_out_bwd(dout, out, o, r, bn2, gamma2, bnr, gammar, want_g, drop_p, seed, training, dpool=None, relu_mask=None,
                   want_bn_grads=False):
-    """-> dO, dR (or None), g (or None), stats2 [2,C] (sum gd, sum gd*ohat), statsr, dbias_o, dbias_r (float32);
+    """-> dO, dR (or None), g (or None), stats2 [2,C] (sum gd, sum gd*ohat), statsr, dbias_o, dbias_r (float32 [C]);
     with want_bn_grads additionally (dgamma2, dbeta2, dgammar, dbetar) as float32, written by the apply pass.
     The incoming gradient is dout (stored tensor) and/or dpool [B,C] float32, constant over (t,v).  The ReLU
     decisions are read from relu_mask (as written by block_out_fwd) when given, else from out."""
     B, Cc, T, V = o.shape
     rows = B * T * V
-    acc = stats_alloc((5, Cc), o.device)
+    acc = stats_alloc((6, Cc), o.device)
     stats2, statsr = acc[0:2], acc[2:4]
-    dbf = acc[4].view(torch.float32)                      # zeroed: two float32 sums in the space of one double row
-    dbo, dbr = dbf[:Cc], dbf[Cc:]
+    dbo, dbr = acc[4], acc[5]                             # zeroed double sums
     has_r = r is not None
     bng = torch.empty((4, Cc), dtype=torch.float32, device=o.device) if want_bn_grads else None
     args = [L.dtype_code(o.dtype), 0, L.ptr(dout), L.ptr(dpool), T * V, L.ptr(out) if relu_mask is None else None, L.ptr(relu_mask), L.ptr(o), L.ptr(r), L.ptr(bn2.mean), L.ptr(bn2.rstd), L.ptr(gamma2),
@@ -344,11 +343,10 @@ def block_out_bwd(dout, out, o, r, bn2, gamma2, bnr, gammar, want_g, drop_p, see
     args[1] = 1
     args[17], args[18], args[19] = L.ptr(dO), L.ptr(dR), L.ptr(g)
     _launch((str(o.dtype), 1, rows, Cc, has_r, want_g), "stgcn_block_out_bwd", *args)
-    # the bias sums leave this function (they become .grad of the conv biases): hand out memory of their own, not
-    # views of the statistics arena, which the next training forward clears (an elementwise kernel rather than
-    # clone(), which is a device-to-device memcpy: a captured step then consists of kernel nodes only)
-    dbf = dbf.mul(1.0)
-    dbo, dbr = dbf[:Cc], dbf[Cc:]
+    # the bias sums leave this function (they become .grad of the conv biases): float32 memory of their own, not views
+    # of the statistics arena, which the next training forward clears
+    dbf = acc[4:6].float()
+    dbo, dbr = dbf[0], dbf[1]
     res = (dO, dR, g, stats2, (statsr if has_r else None), dbo, (dbr if has_r else None))
     if want_bn_grads:
         res = res + ((bng[0], bng[1], bng[2] if has_r else None, bng[3] if has_r else None),)

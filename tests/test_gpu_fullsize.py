@@ -192,8 +192,8 @@ def test_model_full_batch_train_repeats_bit_for_bit(net, dtype):
     F.OVERLAP_WGRAD = was
     (l0, g0, b0), (l1, g1, b1) = res
     assert torch.equal(l0, l1)
-    differ = [k for k in g0 if not (k.endswith("tcn.2.bias") or k.endswith("residual.0.bias")) and not torch.equal(g0[k], g1[k])]
-    assert not differ, differ[:5]                         # the two skipped kinds are float32 atomic sums of exact zeros' noise
+    differ = [k for k in g0 if not torch.equal(g0[k], g1[k])]
+    assert not differ, differ[:5]
     assert all(torch.equal(b0[k], b1[k]) for k in b0)     # running statistics
 
 

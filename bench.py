@@ -164,7 +164,7 @@ def main():
         local = local % max(ndev, 1)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    if world > 1 or (os.environ.get("STGCN_DDP_FORCE") == "1" and "RANK" in os.environ):   # FORCE: a one-rank RCCL group
         backend = os.environ.get("STGCN_DIST_BACKEND", "nccl")          # "nccl" is RCCL on ROCm
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
@@ -187,7 +187,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -302,7 +302,7 @@ def main():
         if other is not None:
             line[other_name] = other
         print(json.dumps(line))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

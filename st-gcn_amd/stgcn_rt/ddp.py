@@ -9,6 +9,8 @@ averaged with a few large all-reduces over RCCL/xGMI.  Buckets follow reverse ex
 accumulated, so communication overlaps the rest of backward.  The optimizer step is one HIP
 kernel over the flat buffers (torch.optim.SGD semantics: processor/recognition.py:46-53).
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -132,6 +134,9 @@ class GradBucketer:
         self.flat = flat
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        # collectives run when there is more than one rank -- or, with STGCN_DDP_FORCE=1, in a one-rank group too: the
+        # whole RCCL path (hook-launched asynchronous all-reduces, broadcast, waits) on a box with a single GPU
+        self.distributed = self.world > 1 or (os.environ.get("STGCN_DDP_FORCE") == "1" and dist.is_available() and dist.is_initialized())
         self.buckets = []                     # (start, end, [param indices])
         start, idxs, nbytes = 0, [], 0
         for i, n in enumerate(flat.sizes):
@@ -151,7 +156,7 @@ class GradBucketer:
         self.launched = []
         self.trace = []                       # ("grad", param index) / ("launch", bucket) in the order they happened
         self.hooks_enabled = True             # off while a step is captured into / replayed from a HIP graph
-        if self.world > 1:
+        if self.distributed:
             for i, p in enumerate(flat.params):
                 p.register_post_accumulate_grad_hook(self._make_hook(i))
         self.reset()
@@ -184,7 +189,7 @@ class GradBucketer:
         """Launch whatever was not triggered by hooks (unused parameters), wait for all buckets.
         Gradients hold the SUM over ranks afterwards; the optimizer divides by the world size.
         Single process: one multi-tensor copy brings every gradient into the flat buffer."""
-        if self.world > 1:
+        if self.distributed:
             for b in range(len(self.buckets)):
                 if b not in self.launched:
                     self._launch(b)
@@ -197,7 +202,7 @@ class GradBucketer:
     def reduce_flat(self):
         """All buckets of an already gathered flat gradient (a replayed HIP graph leaves it complete): every
         all-reduce is launched, then all are waited for.  Returns the scale the optimizer applies."""
-        if self.world > 1:
+        if self.distributed:
             hs = [all_reduce_sum(self.flat.grad[s:e], self.group) for (s, e, _) in self.buckets]
             for h in hs:
                 h.wait()
@@ -248,7 +253,7 @@ class Trainer:
         self._eager_steps = 0
 
     def broadcast_from_rank0(self):
-        if self.bucketer.world > 1:
+        if self.bucketer.distributed:
             broadcast0(self.flat.flat)
             for b in self.model.buffers():
                 broadcast0(b)

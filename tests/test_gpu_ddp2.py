@@ -27,3 +27,17 @@ def test_trainer_two_ranks(tmp_path):
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import ddp2_check
     ddp2_check.verify(str(tmp_path))
+
+
+def test_trainer_over_rccl_one_rank():
+    """The RCCL code path itself on the box's one GPU: a one-rank "nccl" group (tools/rccl_one_rank.py)."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, STGCN_DDP_FORCE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "tools", "rccl_one_rank.py")]
+    p = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=170, text=True)
+    print("\n".join(l for l in p.stdout.splitlines() if "RCCL" in l or "graph=" in l))
+    assert p.returncode == 0 and "RCCL_ONE_RANK_OK" in p.stdout, p.stdout[-3000:]

@@ -266,7 +266,7 @@ class Trainer:
         out = self.model(data)
         loss = self.loss_fn(out, label)
         loss.backward()
-        return loss
+        return loss.detach()                  # not the graph's root: a kept loss would keep every autograd node of the step alive
 
     def _capture(self, data, label):
         from . import ops as P

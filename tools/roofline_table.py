@@ -1,0 +1,38 @@
+"""Per-kernel roofline table of one training step from bench.py's event table (`bench.py --kernel-table`, stderr):
+every timed launch shape with its time per step, achieved TFLOP/s and GB/s (algorithmic work: bench.kernel_work), the
+roofline that binds it -- the larger of flops/peak and bytes/peak -- and the fraction of that roofline.
+
+    python tools/roofline_table.py profiles/r02_bench_event_tables.txt [bf16|fp32]
+"""
+import ast
+import re
+import sys
+
+PEAK = {"bf16": (2500.0, 8000.0), "fp32": (157.3, 8000.0)}      # TFLOP/s (dense MFMA), GB/s (HBM3E)
+
+
+def main():
+    path, which = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else "bf16")
+    tf_peak, bw_peak = PEAK[which]
+    rows, on = [], False
+    for line in open(path):
+        if line.startswith(("bf16:", "fp32:")):
+            on = line.startswith(which + ":")
+            continue
+        m = re.match(r"\s+([\d.]+) ms x(\d+)\s+([\d.]+) TFLOP/s\s+([\d.]+) GB/s\s+(\(.*\))\s*$", line)
+        if on and m:
+            ms, n, tf, gb, key = float(m.group(1)), int(m.group(2)), float(m.group(3)), float(m.group(4)), ast.literal_eval(m.group(5))
+            rows.append((ms * n, ms, n, tf, gb, key))
+    total = sum(r[0] for r in rows)
+    print("| kernel (entry point, shape) | launches x ms | % of step | TFLOP/s | GB/s | bound | fraction |")
+    print("|---|---|---|---|---|---|---|")
+    for tot, ms, n, tf, gb, key in sorted(rows, key=lambda r: -r[0]):
+        f_m, f_h = tf / tf_peak, gb / bw_peak
+        bound, frac = ("mfma", f_m) if f_m >= f_h else ("hbm", f_h)
+        shape = " ".join(str(k) for k in key[2:])
+        print("| %s %s | %d x %.3f | %.1f | %.0f | %.0f | %s | %.2f |" % (key[0].replace("stgcn_", ""), shape, n, ms, 100 * tot / total, tf, gb, bound, frac))
+    print("\ntotal of the timed launches %.2f ms" % total)
+
+
+if __name__ == "__main__":
+    main()

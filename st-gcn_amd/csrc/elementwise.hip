@@ -5,6 +5,7 @@
 // (fixed channels, so per-channel parameters live in registers and per-channel sums reduce in
 // registers -> LDS -> one double atomic per channel per workgroup).
 #include "stgcn_common.h"
+#include <cstdlib>
 
 // NT = threads per workgroup
 template <typename T, int NT = 256> struct RowMap {
@@ -136,10 +137,10 @@ struct BlockOutArgs {
     const uint32_t* seed_step;   // optional device counter mixed into the seed (see stgcn_block_out_fwd)
 };
 
-template <typename T>
-__global__ __launch_bounds__(256) void block_out_fwd_kernel(BlockOutArgs a) {
+template <typename T, int NT = 256>
+__global__ __launch_bounds__(NT) void block_out_fwd_kernel(BlockOutArgs a) {
     constexpr int VEC = ET<T>::VEC;
-    RowMap<T> m(a.C);
+    RowMap<T, NT> m(a.C);
     if (!m.active) return;
     if (a.thr && a.seed_step) a.seed += *a.seed_step * STGCN_SEED_STEP_MUL;
     float s2[VEC], b2[VEC], sr[VEC], br[VEC];
@@ -206,10 +207,14 @@ extern "C" int stgcn_block_out_fwd(int dtype, const void* o, const void* res, vo
     a.rows = rows; a.C = C; a.seed = seed; a.thr = drop_thr(drop_p); a.keep_scale = 1.f / (1.f - drop_p);
     if (dtype == STGCN_BF16) {
         if (!ew_ok<bf16>(C)) return STGCN_ERR_ARG;
-        hipLaunchKernelGGL(block_out_fwd_kernel<bf16>, dim3(ew_grid(rows, ew_rpi<bf16>(C))), dim3(256), 0, (hipStream_t)stream, a);
+        const int cvs = C / ET<bf16>::VEC;
+        if (cvs <= 64 && (cvs & (cvs - 1)) == 0)         // as bn_bwd_apply: 512 workgroups of 512 threads (1-2 % here)
+            hipLaunchKernelGGL((block_out_fwd_kernel<bf16, 512>), dim3(ew_grid(rows, 512 / cvs, 512)), dim3(512), 0, (hipStream_t)stream, a);
+        else
+            hipLaunchKernelGGL((block_out_fwd_kernel<bf16, 256>), dim3(ew_grid(rows, ew_rpi<bf16>(C))), dim3(256), 0, (hipStream_t)stream, a);
     } else if (dtype == STGCN_F32) {
         if (!ew_ok<float>(C)) return STGCN_ERR_ARG;
-        hipLaunchKernelGGL(block_out_fwd_kernel<float>, dim3(ew_grid(rows, ew_rpi<float>(C))), dim3(256), 0, (hipStream_t)stream, a);
+        hipLaunchKernelGGL((block_out_fwd_kernel<float, 256>), dim3(ew_grid(rows, ew_rpi<float>(C))), dim3(256), 0, (hipStream_t)stream, a);
     } else return STGCN_ERR_ARG;
     return hipGetLastError() == hipSuccess ? STGCN_OK : STGCN_ERR_LAUNCH;
 }
@@ -431,7 +436,9 @@ static void block_out_bwd_launch(const BlockOutBwdArgs& a, int pass, hipStream_t
         else hipLaunchKernelGGL((block_out_bwd_reduce_kernel<T, false, BOB_NR, 256>), dim3(gr), dim3(256), 0, st, a);
     } else {
         const int cvs = a.C / ET<T>::VEC;
-        if (a.dR) hipLaunchKernelGGL((block_out_bwd_apply_kernel<T, true, BOB_NA, 256>), dim3(gr), dim3(256), 0, st, a);
+        if (a.dR && cvs <= 64 && (cvs & (cvs - 1)) == 0)      // 512 threads: the conv-residual form needs 168 registers
+            hipLaunchKernelGGL((block_out_bwd_apply_kernel<T, true, BOB_NA, 512>), dim3(ew_grid(a.rows, 512 / cvs, 2 * BOB_GRID)), dim3(512), 0, st, a);
+        else if (a.dR) hipLaunchKernelGGL((block_out_bwd_apply_kernel<T, true, BOB_NA, 256>), dim3(gr), dim3(256), 0, st, a);
         else if (cvs <= 64 && (cvs & (cvs - 1)) == 0)
             hipLaunchKernelGGL((block_out_bwd_apply_kernel<T, false, BOB_NA, BOB_NT>), dim3(ew_grid(a.rows, BOB_NT / cvs, BOB_GRID)), dim3(BOB_NT), 0, st, a);
         else hipLaunchKernelGGL((block_out_bwd_apply_kernel<T, false, BOB_NA, 256>), dim3(gr), dim3(256), 0, st, a);
@@ -477,12 +484,12 @@ struct BnBwdArgs {
     const double* stats; double count; size_t rows; int C; int training;
     float* dgamma; float* dbeta;             // optional: dbeta = stats[0..C), dgamma = stats[C..2C) as float32
 };
-template <typename T>
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a) {
+template <typename T, int NT = 256>
+__global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(BnBwdArgs a) {
     constexpr int VEC = ET<T>::VEC;
-    RowMap<T> m(a.C);
+    RowMap<T, NT> m(a.C);
     if (blockIdx.x == 0 && a.stats) {
-        for (int c = threadIdx.x; c < a.C; c += 256) {
+        for (int c = threadIdx.x; c < a.C; c += NT) {
             if (a.dbeta) a.dbeta[c] = (float)a.stats[c];
             if (a.dgamma) a.dgamma[c] = (float)a.stats[a.C + c];
         }
@@ -515,10 +522,16 @@ extern "C" int stgcn_bn_bwd_apply(int dtype, const void* g, const void* y, void*
     a.rows = rows; a.C = C; a.training = training; a.dgamma = dgamma; a.dbeta = dbeta;
     if (dtype == STGCN_BF16) {
         if (!ew_ok<bf16>(C)) return STGCN_ERR_ARG;
-        hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16>, dim3(ew_grid(rows, ew_rpi<bf16>(C))), dim3(256), 0, (hipStream_t)stream, a);
+        // rows of <= 64 channel vectors: 512 workgroups of 512 threads (two per CU) walk the rows with a grid stride --
+        // 10 % faster than up to 2048 workgroups of 256 (0.0745 vs 0.0826 ms at 960 000 rows x 64 channels)
+        const int cvs = C / ET<bf16>::VEC;
+        if (cvs <= 64 && (cvs & (cvs - 1)) == 0)
+            hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16, 512>), dim3(ew_grid(rows, 512 / cvs, 512)), dim3(512), 0, (hipStream_t)stream, a);
+        else
+            hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16, 256>), dim3(ew_grid(rows, ew_rpi<bf16>(C))), dim3(256), 0, (hipStream_t)stream, a);
     } else if (dtype == STGCN_F32) {
         if (!ew_ok<float>(C)) return STGCN_ERR_ARG;
-        hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(ew_grid(rows, ew_rpi<float>(C))), dim3(256), 0, (hipStream_t)stream, a);
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<float, 256>), dim3(ew_grid(rows, ew_rpi<float>(C))), dim3(256), 0, (hipStream_t)stream, a);
     } else return STGCN_ERR_ARG;
     return hipGetLastError() == hipSuccess ? STGCN_OK : STGCN_ERR_LAUNCH;
 }

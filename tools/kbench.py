@@ -85,7 +85,7 @@ def make(case, dtype):
         g2, gr = mk(), mk()
         mask = torch.randint(-32768, 32767, (rows * Cc * o.element_size() // 16,), dtype=torch.int16, device=DEV)
         acc = torch.zeros((4, Cc), dtype=torch.float64, device=DEV)
-        dbf = torch.zeros((2, Cc), dtype=torch.float32, device=DEV)
+        dbf = torch.zeros((2, Cc), dtype=torch.float64, device=DEV)
         dO, dR, g = torch.empty_like(o), torch.empty_like(o), torch.empty_like(o)
         ps = 0 if name.startswith("bob0") else 1
         args = [L.dtype_code(o.dtype), ps, L.ptr(dout), None, Tt * V, None, L.ptr(mask), L.ptr(o), L.ptr(r), L.ptr(bn2.mean), L.ptr(bn2.rstd), L.ptr(g2),

@@ -150,7 +150,8 @@ int stgcn_augment(const float* in, float* out, const int* shift, const float* ca
                   const float* tx, const float* ty, int N, int C, int Tin, int Tout, int VM, void* stream);
 
 /* data_bn: BatchNorm1d over channel v*C+c of x[N,C,T,V,M] (float32) and the two permutes around it.
- * Replaces: net/st_gcn.py:72-78 (output is the channels-last [N*M][T][V][Cp] activation, Cp >= C zero padded). */
+ * Replaces: net/st_gcn.py:72-78 (output is the channels-last [N*M][T][V][Cp] activation, Cp >= C zero padded, Cp a
+ * multiple of one 16-byte piece: 8 bf16 / 4 f32 channels). */
 int stgcn_data_bn_stats(const float* x, double* stats, int N, int C, int T, int V, int M, void* stream);
 int stgcn_data_bn_apply(int dtype, const float* x, void* out, const float* scale, const float* shift,
                         int N, int C, int T, int V, int M, int Cp, void* stream);

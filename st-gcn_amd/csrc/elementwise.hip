@@ -604,13 +604,20 @@ __global__ __launch_bounds__(256) void data_bn_apply_kernel(const float* x, T* o
         const int t = (int)(rest % T_); rest /= T_;
         const int mm = (int)(rest % M);
         const int n = (int)(rest / M);
-        for (int c = 0; c < Cp; ++c) {
-            float val = 0.f;
-            if (c < C) {
-                const float xv = x[((((size_t)n * C + c) * T_ + t) * V + v) * M + mm];
-                val = fmaf(xv, scale[v * C + c], shift[v * C + c]);
+        // one 16-byte store per VEC channels (Cp is a multiple of VEC: whole k-steps)
+        constexpr int VEC = ET<T>::VEC;
+        for (int c0 = 0; c0 < Cp; c0 += VEC) {
+            float f[VEC];
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                const int c = c0 + j;
+                f[j] = 0.f;
+                if (c < C) {
+                    const float xv = x[((((size_t)n * C + c) * T_ + t) * V + v) * M + mm];
+                    f[j] = fmaf(xv, scale[v * C + c], shift[v * C + c]);
+                }
             }
-            store_elem<T>(out, i * Cp + c, val);
+            *(i32x4*)((T*)out + i * Cp + c0) = pack16<T>(f);
         }
     }
 }
@@ -710,7 +717,10 @@ extern "C" int stgcn_augment(const float* in, float* out, const int* shift, cons
 
 extern "C" int stgcn_data_bn_stats(const float* x, double* stats, int N, int C, int T, int V, int M, void* stream) {
     if (!x || !stats || N < 1 || C < 1 || T < 1 || V < 1 || M < 1) return STGCN_ERR_ARG;
-    int gy = (T + 31) / 32; if (gy > 16) gy = 16;
+    // every workgroup ends in 2 V double atomics on the same V*C addresses: few, long workgroups (about two per CU)
+    int gy = (2 * stgcn_num_cus() + N * C - 1) / (N * C);
+    if (gy > (T + 31) / 32) gy = (T + 31) / 32;
+    if (gy < 1) gy = 1;
     const dim3 grid((unsigned)(N * C), (unsigned)gy);
     if (V * M <= 256)
         hipLaunchKernelGGL(data_bn_stats_kernel<true>, grid, dim3(256), 2 * (size_t)(256 / (V * M)) * V * M * sizeof(float), (hipStream_t)stream, x, stats, N, C, T, V, M);
@@ -721,6 +731,7 @@ extern "C" int stgcn_data_bn_stats(const float* x, double* stats, int N, int C, 
 extern "C" int stgcn_data_bn_apply(int dtype, const float* x, void* out, const float* scale, const float* shift,
                                    int N, int C, int T, int V, int M, int Cp, void* stream) {
     if (!x || !out || !scale || !shift || Cp < C) return STGCN_ERR_ARG;
+    if (Cp % (dtype == STGCN_BF16 ? 8 : 4) != 0) return STGCN_ERR_ARG;       // rows are written in 16-byte pieces
     const size_t total = (size_t)N * M * T * V;
     unsigned g = (unsigned)((total + 255) / 256); if (g > 4096) g = 4096;
     if (dtype == STGCN_BF16) hipLaunchKernelGGL(data_bn_apply_kernel<bf16>, dim3(g), dim3(256), 0, (hipStream_t)stream, x, (bf16*)out, scale, shift, N, C, T, V, M, Cp);
@@ -749,11 +760,12 @@ extern "C" int stgcn_data_bn_bwd(int dtype, const void* dx0, const float* x, con
 
 // ------------------------------------------------------------------------------------------
 // Head: global average pool over (T, V), mean over persons, 1x1 classifier.
-template <typename T>
-__global__ __launch_bounds__(256) void pool_fwd_kernel(const T* feat, float* pooled, int R, int C) {
-    // workgroup per (b, channel-vector group); feat [B][R][C]
+template <typename T, int NT = 256>
+__global__ __launch_bounds__(NT) void pool_fwd_kernel(const T* feat, float* pooled, int R, int C) {
+    // workgroup per sample b; feat [B][R][C].  One workgroup streams a whole sample (a fixed summation order), so the
+    // loads in flight are what counts: NT = 1024 threads, 8 loads each
     constexpr int VEC = ET<T>::VEC;
-    RowMap<T> m(C);
+    RowMap<T, NT> m(C);
     float s[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; ++j) s[j] = 0.f;
@@ -781,7 +793,7 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(const T* feat, float* poo
             for (int j = 0; j < VEC; ++j) s[j] += f[j];
         }
     }
-    __shared__ float red[256 * VEC];
+    __shared__ float red[NT * VEC];
 #pragma unroll
     for (int j = 0; j < VEC; ++j) red[threadIdx.x * VEC + j] = m.active ? s[j] : 0.f;
     __syncthreads();
@@ -796,8 +808,8 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(const T* feat, float* poo
 }
 extern "C" int stgcn_pool_fwd(int dtype, const void* feat, float* pooled, int B, int R, int C, void* stream) {
     if (!feat || !pooled || B < 1 || R < 1) return STGCN_ERR_ARG;
-    if (dtype == STGCN_BF16) { if (!ew_ok<bf16>(C)) return STGCN_ERR_ARG; hipLaunchKernelGGL(pool_fwd_kernel<bf16>, dim3(B), dim3(256), 0, (hipStream_t)stream, (const bf16*)feat, pooled, R, C); }
-    else if (dtype == STGCN_F32) { if (!ew_ok<float>(C)) return STGCN_ERR_ARG; hipLaunchKernelGGL(pool_fwd_kernel<float>, dim3(B), dim3(256), 0, (hipStream_t)stream, (const float*)feat, pooled, R, C); }
+    if (dtype == STGCN_BF16) { if (!ew_ok<bf16>(C)) return STGCN_ERR_ARG; hipLaunchKernelGGL((pool_fwd_kernel<bf16, 1024>), dim3(B), dim3(1024), 0, (hipStream_t)stream, (const bf16*)feat, pooled, R, C); }
+    else if (dtype == STGCN_F32) { if (!ew_ok<float>(C)) return STGCN_ERR_ARG; hipLaunchKernelGGL((pool_fwd_kernel<float, 1024>), dim3(B), dim3(1024), 0, (hipStream_t)stream, (const float*)feat, pooled, R, C); }
     else return STGCN_ERR_ARG;
     return hipGetLastError() == hipSuccess ? STGCN_OK : STGCN_ERR_LAUNCH;
 }
@@ -819,14 +831,28 @@ __global__ void head_fc_fwd_kernel(const float* pooled, const float* W, const fl
     }
 }
 // dW[j][c] = sum_n dlog[n][j]*pm[n][c]; db[j] = sum_n dlog[n][j]; dpm[n][c] = sum_j dlog[n][j] W[j][c]
-__global__ void head_fc_bwd_kernel(const float* dlog, const float* pooled, const float* W, float* dW, float* db, float* dpm,
-                                   int N, int M, int C, int ncls) {
+__global__ void head_fc_bwd_kernel(const float* __restrict__ dlog, const float* __restrict__ pooled, const float* __restrict__ W,
+                                   float* __restrict__ dW, float* __restrict__ db, float* __restrict__ dpm, int N, int M, int C, int ncls) {
     const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t nW = (size_t)ncls * C, nP = (size_t)N * C;
     if (tid < nW) {
         const int j = (int)(tid / C), c = (int)(tid % C);
+        // the sum over n in its natural order (the result must not depend on the unrolling), the loads of 8 samples
+        // issued together
         float s = 0.f;
-        for (int n = 0; n < N; ++n) {
+        int n = 0;
+        for (; n + 8 <= N; n += 8) {
+            float pm[8], dl[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                pm[u] = 0.f;
+                for (int mm = 0; mm < M; ++mm) pm[u] += pooled[((size_t)(n + u) * M + mm) * C + c];
+                dl[u] = dlog[(size_t)(n + u) * ncls + j];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s = fmaf(dl[u], pm[u] / (float)M, s);
+        }
+        for (; n < N; ++n) {
             float pm = 0.f;
             for (int mm = 0; mm < M; ++mm) pm += pooled[((size_t)n * M + mm) * C + c];
             s = fmaf(dlog[(size_t)n * ncls + j], pm / (float)M, s);

@@ -641,6 +641,7 @@ __global__ __launch_bounds__(256) void data_bn_bwd_kernel(const T* dx0, const fl
             const int v = ch / C, c = ch - v * C;
             const float mu = mean[ch], rs = rstd[ch];
             float s = 0.f, s2 = 0.f;
+#pragma unroll 4
             for (int t = t0 + r; t < t1; t += R) {
                 const float d = load_elem<T>(dx0, (((size_t)b * T_ + t) * V + v) * Cp + c);
                 const float xv = x[((((size_t)n * C + c) * T_ + t) * V + v) * M + mm];
@@ -742,7 +743,10 @@ extern "C" int stgcn_data_bn_apply(int dtype, const float* x, void* out, const f
 extern "C" int stgcn_data_bn_bwd(int dtype, const void* dx0, const float* x, const float* mean, const float* rstd, double* stats,
                                  int N, int C, int T, int V, int M, int Cp, void* stream) {
     if (!dx0 || !x || !mean || !rstd || !stats || Cp < C) return STGCN_ERR_ARG;
-    int gy = (T + 31) / 32; if (gy > 16) gy = 16;
+    // as data_bn_stats: every workgroup ends in 2 V C double atomics on the same addresses -- about two workgroups per CU
+    int gy = (2 * stgcn_num_cus() + N * M - 1) / (N * M);
+    if (gy > (T + 31) / 32) gy = (T + 31) / 32;
+    if (gy < 1) gy = 1;
     const bool fixed = V * C <= 256;
     const size_t lds = 2 * (size_t)(fixed ? 256 / (V * C) : 1) * V * C * sizeof(float);
     if (lds > 64 * 1024) return STGCN_ERR_ARG;

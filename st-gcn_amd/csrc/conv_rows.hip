@@ -282,6 +282,10 @@ int conv_big_try(int dtype, const void* in, const void* w, void* out, const floa
                  double* stats, int B, int Tin, int Tout, int V, int Cin, int Cout, int ntaps, int stride, int pad, int dil,
                  int transposed, hipStream_t stream);
 
+// streaming path for the strided 1-tap convolution in bf16 (conv1s.hip); -1 = shape not covered
+int conv1s_try(const void* in, const void* w, void* out, const float* bias, double* stats,
+               int B, int Tin, int Tout, int V, int Cin, int Cout, int stride, int transposed, hipStream_t stream);
+
 // C-ABI ------------------------------------------------------------------------------------
 extern "C" int stgcn_conv_rows(int dtype, const void* in, const void* w_packed, void* out,
                                const float* bias, const float* pro_scale, const float* pro_shift,
@@ -301,6 +305,10 @@ extern "C" int stgcn_conv_rows(int dtype, const void* in, const void* w_packed, 
         (epilogue == EPI_PLAIN || epilogue == EPI_ADD_RELU || (aux && ep_scale && ep_shift && ep_mean && ep_rstd))) {
         const int rc = conv_t9_try(in, w_packed, out, bias, pro_scale, pro_shift, epilogue, aux, ep_scale, ep_shift, ep_mean, ep_rstd,
                                    stats, B, Tin, V, Cin, Cout, ntaps, transposed, (hipStream_t)stream);
+        if (rc >= 0) return rc;
+    }
+    if (dtype == STGCN_BF16 && ntaps == 1 && stride == 2 && pad == 0 && dil == 1 && epilogue == EPI_PLAIN && !pro_scale) {
+        const int rc = conv1s_try(in, w_packed, out, bias, stats, B, Tin, Tout, V, Cin, Cout, stride, transposed, (hipStream_t)stream);
         if (rc >= 0) return rc;
     }
     if ((dtype == STGCN_BF16 || dtype == STGCN_F32) && B > 0 && Tin > 0 && Tout > 0 &&

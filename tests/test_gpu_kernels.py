@@ -71,6 +71,10 @@ CONV_CASES = [
     (2, 256, 400, 10, 18, 1, 1, 0, False),       # per-position classifier of Kinetics: ragged last column tile
     (2, 128, 80, 20, 25, 9, 1, 4, True),
     (2, 64, 40, 33, 25, 9, 1, 4, True),
+    # strided 1-tap (the residual branch): 64-column passes, 256 input channels, odd frame count, several blocks per wave
+    (2, 128, 64, 21, 25, 1, 2, 0, False),
+    (3, 256, 128, 30, 25, 1, 2, 0, False),
+    (40, 64, 128, 299, 25, 1, 2, 0, False),
 ]
 
 
@@ -293,7 +297,8 @@ def test_gcn_kernels_stay_inside_their_inputs(rt, lay, strat, B, Cin, Cout, T, d
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
 @pytest.mark.parametrize("case", [(1, 64, 8, 7, 18, 3, 1, 1, 1), (2, 64, 24, 9, 25, 9, 2, 4, 1), (1, 128, 40, 6, 25, 1, 1, 0, 1),
-                                  (1, 64, 64, 11, 18, 3, 2, 2, 2), (2, 64, 64, 10, 25, 5, 3, 0, 1)], ids=lambda c: "x".join(map(str, c)))
+                                  (1, 64, 64, 11, 18, 3, 2, 2, 2), (2, 64, 64, 10, 25, 5, 3, 0, 1),
+                                  (2, 64, 128, 13, 25, 1, 2, 0, 1), (1, 128, 64, 8, 18, 1, 2, 0, 1)], ids=lambda c: "x".join(map(str, c)))
 def test_conv_kernels_stay_inside_their_inputs(rt, case, dtype):
     """The temporal convolution at narrow / ragged output widths, strides up to 3 and dilation, inputs fenced with NaN."""
     B, Cin, Cout, T, V, kt, stride, pad, dil = case

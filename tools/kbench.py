@@ -46,7 +46,7 @@ def make(case, dtype):
         if name == "gcn_agrad":
             return lambda: R.gcn_agrad(x, wp, bias, dy)
         return lambda: R.gcn_wgrad(x, dy, adj)
-    if name in ("conv", "conv_t", "conv_t_epi", "conv_wgrad", "conv1", "conv1_wgrad"):
+    if name in ("conv", "conv_np", "conv_ns", "conv_t", "conv_t_epi", "conv_wgrad", "conv1", "conv1_t", "conv1_wgrad"):
         kt = 1 if name.startswith("conv1") else 9
         pad = (kt - 1) // 2
         Tout = (Tin + 2 * pad - kt) // stride + 1
@@ -57,11 +57,12 @@ def make(case, dtype):
         sh = torch.randn((Cin,), device=DEV) * 0.1
         stats = torch.zeros(2 * Cout, dtype=torch.float64, device=DEV)
         do = act(Cout, Tout, dtype)
-        if name in ("conv", "conv1"):
+        if name in ("conv", "conv1", "conv_np", "conv_ns"):    # _np: without the BatchNorm+ReLU prologue; _ns: without statistics
             wp = R.pack_conv_w(W, dtype)
-            pro = (sc, sh) if kt == 9 else None
-            return lambda: R.conv_rows(x, wp, Cout, Tout, bias=bias, pro=pro, stats=stats, ntaps=kt, stride=stride, pad=pad)
-        if name == "conv_t":
+            pro = (sc, sh) if (kt == 9 and name != "conv_np") else None
+            st = None if name == "conv_ns" else stats
+            return lambda: R.conv_rows(x, wp, Cout, Tout, bias=bias, pro=pro, stats=st, ntaps=kt, stride=stride, pad=pad)
+        if name in ("conv_t", "conv1_t"):
             wt = R.pack_conv_wt(W, dtype)
             return lambda: R.conv_rows(do, wt, Cin, Tin, ntaps=kt, stride=stride, pad=pad, transposed=True)
         if name == "conv_t_epi":            # data gradient fused with the ReLU mask and BatchNorm-backward sums
@@ -127,11 +128,19 @@ def main():
     if a.lib:
         L._LIB_PATH = os.path.abspath(a.lib)
     L.load()
+    import time
+    first = True
     for case in a.cases:
         fn = make(case, dtype)
-        for _ in range(2):
-            fn()
-        torch.cuda.synchronize()
+        # the first launches of a process run at a lower clock: keep the device busy for a while before timing
+        t_end = time.time() + (0.5 if first else 0.05)
+        first = False
+        while True:
+            for _ in range(10):
+                fn()
+            torch.cuda.synchronize()
+            if time.time() >= t_end:
+                break
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)
         e0.record()

@@ -32,6 +32,18 @@ def main():
         shape = " ".join(str(k) for k in key[2:])
         print("| %s %s | %d x %.3f | %.1f | %.0f | %.0f | %s | %.2f |" % (key[0].replace("stgcn_", ""), shape, n, ms, 100 * tot / total, tf, gb, bound, frac))
     print("\ntotal of the timed launches %.2f ms" % total)
+    # families: time per step, share, time-weighted fraction of the binding roofline and its range over launch shapes
+    fam_of = lambda name: ("temporal conv forward / data gradient" if name == "stgcn_conv_rows" else
+                           "temporal conv weight gradient" if name == "stgcn_conv_wgrad" else
+                           "graph conv forward, dX, dW, dA" if name.startswith("stgcn_gcn") else "elementwise")
+    fams = {}
+    for tot, ms, n, tf, gb, key in rows:
+        fams.setdefault(fam_of(key[0]), []).append((tot, max(tf / tf_peak, gb / bw_peak)))
+    print("\n| family | ms per step | % of step | time-weighted fraction (range) |\n|---|---|---|---|")
+    for name, v in sorted(fams.items(), key=lambda kv: -sum(t for t, _ in kv[1])):
+        t = sum(x for x, _ in v)
+        print("| %s | %.2f | %.0f | %.2f (%.2f-%.2f) |" % (name, t, 100 * t / total, sum(x * f for x, f in v) / t, min(f for _, f in v), max(f for _, f in v)))
+    print("| all timed launches | %.2f | 100 | %.2f |" % (total, sum(x * f for v in fams.values() for x, f in v) / total))
 
 
 if __name__ == "__main__":

@@ -14,6 +14,10 @@
 //     BM = 256 (or 128) virtual output rows.  Per 64-channel chunk of Cin the window of input rows all taps need is
 //     staged once in LDS (BatchNorm+ReLU prologue applied once per element); taps read their A fragments from it at
 //     per-lane row offsets (a zero row stands in for frames outside the sample).
+//   - GRP (forward, stride 2): the frames a tile's taps touch are twice the tile's own, too many rows for the window
+//     at 256-row tiles.  The taps are then taken in two groups by the parity of their frame offset; a group's window
+//     holds every second frame (the ones of its parity), and a chunk is two phases: stage group 0, run its taps,
+//     stage group 1, run its taps.
 //   - The NEXT window (next chunk, or the first chunk of the next tile) is fetched into registers while the current
 //     chunk's taps run, so global latency hides under 9 x 16 (or 32) MFMAs per wave; weight tiles (128 x 64 per
 //     tap) are double-buffered the same way.
@@ -35,6 +39,7 @@ struct ConvBigArgs {
     int foff[9], wk[9];
     int foff_min, foff_max;
     int tiles_per_sample, zero_row;
+    int gt[3], gmin[2], gmax[2];      // GRP: taps [gt[g], gt[g+1]) form group g, its least and largest frame offset
 };
 
 // scheduling pattern for one k-step: NR LDS reads paired two-by-two behind the first MFMAs, then the remaining MFMAs
@@ -44,8 +49,10 @@ constexpr int CB_WIN_ROWS = 544;    // window capacity in rows
 constexpr int CB_WRS = 128;         // weight-tile row: one unpadded 128-byte chunk, its 16-byte slots XOR-swizzled
 constexpr int CB_NWB = 4;           // weight-tile buffers
 
-template <typename T, int WR, int WC, int MT, int NT, int EPI>
+template <typename T, int WR, int WC, int MT, int NT, int EPI, bool GRP = false>
 __global__ __launch_bounds__(WR * WC * 64) void conv_big_kernel(ConvBigArgs a) {
+    constexpr int NG = GRP ? 2 : 1;                      // tap groups = window phases per chunk
+    constexpr int WFS = GRP ? 2 : 1;                     // frame step inside a window
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int ES = ET<T>::ES;                        // bytes per element
     constexpr int VEC = ET<T>::VEC;                      // elements per 16-byte piece
@@ -97,25 +104,39 @@ __global__ __launch_bounds__(WR * WC * 64) void conv_big_kernel(ConvBigArgs a) {
     }
 
     // tile geometry
-    auto tile_geo = [&](int ti, int& b, int& r0, int& r1, int& flo, int& wrows) {
+    auto tile_geo = [&](int ti, int& b, int& r0, int& r1, int (&flo)[NG], int (&wrows)[NG]) {
         b = ti / a.tiles_per_sample;
         const int tile = ti - b * a.tiles_per_sample;
         r0 = tile * BM;
         r1 = min(r0 + BM, Rv);
         const int tlo = r0 / V, thi = (r1 - 1) / V;
-        int f0 = a.fs * tlo + a.foff_min, f1 = a.fs * thi + a.foff_max;
-        f0 = max(f0, 0);
-        f1 = min(f1, Tin - 1);
-        flo = f0;
-        wrows = max(0, (f1 - f0 + 1) * V);
+        if constexpr (!GRP) {
+            int f0 = a.fs * tlo + a.foff_min, f1 = a.fs * thi + a.foff_max;
+            f0 = max(f0, 0);
+            f1 = min(f1, Tin - 1);
+            flo[0] = f0;
+            wrows[0] = max(0, (f1 - f0 + 1) * V);
+        } else {
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {               // clamped to the sample in steps of two frames: the parity stays
+                int f0 = a.fs * tlo + a.gmin[g], f1 = a.fs * thi + a.gmax[g];
+                if (f0 < 0) f0 += ((1 - f0) >> 1) << 1;
+                if (f1 > Tin - 1) f1 -= ((f1 - Tin + 2) >> 1) << 1;
+                flo[g] = f0;
+                wrows[g] = f1 >= f0 ? (((f1 - f0) >> 1) + 1) * V : 0;
+            }
+        }
     };
     i32x4 pf[NPF];
+    const float inv_v = 1.0f / (float)V;
     auto fetch_win = [&](int b, int flo, int wrows, int chunk) {
         const char* base = (const char*)a.in + (((size_t)b * Tin + flo) * V * (size_t)Cin + (size_t)chunk * CK + sseg * VEC) * ES;
 #pragma unroll
         for (int i = 0; i < NPF; ++i) {
             const int row = srow + RPP * i;
-            if (row < wrows) pf[i] = *(const i32x4*)(base + (size_t)row * Cin * ES);
+            int grow = row;                                // row of the sample, counted from frame flo
+            if constexpr (GRP) grow += (int)(((float)row + 0.5f) * inv_v) * V;      // window frame f is sample frame flo + 2 f
+            if (row < wrows) pf[i] = *(const i32x4*)(base + (size_t)grow * Cin * ES);
         }
     };
     auto commit_win = [&](int wrows, int chunk) {
@@ -180,10 +201,10 @@ __global__ __launch_bounds__(WR * WC * 64) void conv_big_kernel(ConvBigArgs a) {
     const int t_step = xcd_walk ? wpx : (int)gridDim.x;
     int ti = xcd_walk ? (int)(((long long)ntile_total * wq) >> 3) + wr_ : (int)blockIdx.x;
     if (ti >= t_hi) return;
-    int b, r0, r1, flo, wrows;
+    int b, r0, r1, flo[NG], wrows[NG];
     tile_geo(ti, b, r0, r1, flo, wrows);
     if (ntaps > 0) {
-        fetch_win(b, flo, wrows, 0);
+        fetch_win(b, flo[0], wrows[0], 0);
         glds_w_next(0);
         glds_w_next(1);
         glds_w_next(2);
@@ -213,19 +234,22 @@ __global__ __launch_bounds__(WR * WC * 64) void conv_big_kernel(ConvBigArgs a) {
 
         // geometry of the next tile (its first window is prefetched during this tile's last chunk)
         const int tn = ti + t_step;
-        int nb = 0, nr0 = 0, nr1 = 0, nflo = 0, nwrows = 0;
+        int nb = 0, nr0 = 0, nr1 = 0, nflo[NG], nwrows[NG];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) { nflo[g] = 0; nwrows[g] = 0; }
         if (tn < t_hi) tile_geo(tn, nb, nr0, nr1, nflo, nwrows);
 
         if (ntaps > 0) {
             struct Frag { i32x4 af[MT]; i32x4 bf[NT]; };
             // this lane's B-fragment row and (swizzled) slot of k-step 0; k-step s flips bits 5-6 of the offset
             const int wb_off = ((wc * NT) * 32 + l31) * CB_WRS + ((h ^ ((l31 >> 1) & 7)) * 16);
+            int gflo = flo[0];                             // first frame of the window in LDS
             auto a_offsets = [&](int tapi, int (&aoff)[MT]) {
 #pragma unroll
                 for (int m = 0; m < MT; ++m) {
                     const int fr = a.fs * t_out[m] + a.foff[tapi];
                     const bool ok = rvalid[m] && fr >= 0 && fr < Tin;
-                    aoff[m] = (ok ? ((fr - flo) * V + vj[m]) * CB_RS : ZOFF) + h * 16;
+                    aoff[m] = (ok ? (((fr - gflo) / WFS) * V + vj[m]) * CB_RS : ZOFF) + h * 16;
                 }
             };
             auto load_frag = [&](Frag& f, const int (&aoff)[MT], int wbi, int s) {
@@ -243,19 +267,24 @@ __global__ __launch_bounds__(WR * WC * 64) void conv_big_kernel(ConvBigArgs a) {
             };
             Frag fa, fb;
             int aoff[MT], aoff_n[MT];
-            for (int chunk = 0; chunk < nchunks; ++chunk) {
+            for (int ph = 0; ph < nchunks * NG; ++ph) {   // a phase: one window (a chunk; with GRP one tap group of it)
+                const int chunk = GRP ? ph >> 1 : ph;
+                const bool g1 = GRP && (ph & 1);
+                const int tap0 = GRP ? (g1 ? a.gt[1] : a.gt[0]) : 0, tap1 = GRP ? (g1 ? a.gt[2] : a.gt[1]) : ntaps;
+                gflo = g1 ? flo[NG - 1] : flo[0];
                 lds_barrier();                             // previous window / epilogue staging fully consumed
-                commit_win(wrows, chunk);
-                if (chunk + 1 < nchunks) fetch_win(b, flo, wrows, chunk + 1);
-                else if (tn < t_hi) fetch_win(nb, nflo, nwrows, 0);
-                for (int tapi = 0; tapi < ntaps; ++tapi) {
+                commit_win(g1 ? wrows[NG - 1] : wrows[0], chunk);
+                if (GRP && !g1) fetch_win(b, flo[NG - 1], wrows[NG - 1], chunk);
+                else if (chunk + 1 < nchunks) fetch_win(b, flo[0], wrows[0], chunk + 1);
+                else if (tn < t_hi) fetch_win(nb, nflo[0], nwrows[0], 0);
+                for (int tapi = tap0; tapi < tap1; ++tapi) {
                     lds_barrier();                         // weight tile of this step (and a new window) visible
                     const int wnext = (wcur + 1) & (CB_NWB - 1);
-                    if (tapi == 0) {                   // first step on a new window: nothing was prefetched
-                        a_offsets(0, aoff);
+                    if (tapi == tap0) {                // first step on a new window: nothing was prefetched
+                        a_offsets(tapi, aoff);
                         load_frag(fa, aoff, wcur, 0);
                     }
-                    const bool chain = tapi + 1 < ntaps;   // the next step reads the same window
+                    const bool chain = tapi + 1 < tap1;    // the next step reads the same window
                     // 4 k-steps; the fragments of the next one (or of the next step's first) ride under the MFMAs.
                     // The next tap's row offsets are computed behind MFMAs, not in front of the first: both waves
                     // of a SIMD leave the barrier together, and whatever precedes the first MFMA idles the pipe.
@@ -356,7 +385,9 @@ __global__ __launch_bounds__(WR * WC * 64) void conv_big_kernel(ConvBigArgs a) {
                 }
             }
         }
-        b = nb; r0 = nr0; r1 = nr1; flo = nflo; wrows = nwrows;
+        b = nb; r0 = nr0; r1 = nr1;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) { flo[g] = nflo[g]; wrows[g] = nwrows[g]; }
     }
 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // weight tiles fetched ahead for steps that never came
@@ -382,7 +413,7 @@ __global__ __launch_bounds__(WR * WC * 64) void conv_big_kernel(ConvBigArgs a) {
     }
 }
 
-template <typename T, int WR, int WC, int MT, int NT, int EPI>
+template <typename T, int WR, int WC, int MT, int NT, int EPI, bool GRP = false>
 static int launch_conv_big(ConvBigArgs& a, hipStream_t stream) {
     constexpr int BM = WR * MT * 32;
     a.tiles_per_sample = ceil_div_i(a.Tv * a.V, BM);
@@ -393,7 +424,7 @@ static int launch_conv_big(ConvBigArgs& a, hipStream_t stream) {
     const int nct = ceil_div_i(a.Cout, BN);
     int gx = max(1, stgcn_num_cus() / nct);
     if (gx > a.B * a.tiles_per_sample) gx = a.B * a.tiles_per_sample;
-    auto kern = conv_big_kernel<T, WR, WC, MT, NT, EPI>;
+    auto kern = conv_big_kernel<T, WR, WC, MT, NT, EPI, GRP>;
     static std::atomic<uint64_t> lds_ok{0};
     if (stgcn_allow_big_lds((const void*)kern, lds_ok) != STGCN_OK) return STGCN_ERR_LAUNCH;
     hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)nct), dim3(WR * WC * 64), lds, stream, a);
@@ -408,6 +439,29 @@ static int conv_big_win_rows(const ConvBigArgs& a, int BM) {
     return fr * a.V;
 }
 
+// Forward, stride 2, 256-row tiles: the taps sorted into two groups by the parity of their frame offset, each with a
+// window of every second frame.  Returns false when that does not apply or does not fit.
+static bool conv_big_group_taps(ConvBigArgs& a) {
+    if (a.fs != 2 || a.os != 1 || a.ntaps < 2) return false;
+    int foff[9], wk[9], n = 0;
+    for (int g = 0; g < 2; ++g) {
+        a.gt[g] = n;
+        for (int i = 0; i < a.ntaps; ++i)
+            if ((a.foff[i] & 1) == g) {
+                if (n == a.gt[g] || a.foff[i] < a.gmin[g]) a.gmin[g] = a.foff[i];
+                if (n == a.gt[g] || a.foff[i] > a.gmax[g]) a.gmax[g] = a.foff[i];
+                foff[n] = a.foff[i]; wk[n] = a.wk[i]; ++n;
+            }
+    }
+    a.gt[2] = n;
+    if (a.gt[1] == a.gt[0] || a.gt[2] == a.gt[1]) return false;          // one parity only: nothing to split
+    const int nf = (256 - 2) / a.V + 2;
+    for (int g = 0; g < 2; ++g)
+        if (((a.fs * (nf - 1) + a.gmax[g] - a.gmin[g]) / 2 + 1) * a.V > CB_WIN_ROWS) return false;
+    for (int i = 0; i < a.ntaps; ++i) { a.foff[i] = foff[i]; a.wk[i] = wk[i]; }
+    return true;
+}
+
 // dry = true: only report whether the shape fits (0) or not (-1)
 template <typename T>
 static int conv_big_launch_any(ConvBigArgs& a, int epi, hipStream_t stream, bool dry) {
@@ -415,6 +469,12 @@ static int conv_big_launch_any(ConvBigArgs& a, int epi, hipStream_t stream, bool
     for (int i = 0; i < a.ntaps; ++i) {
         if (i == 0 || a.foff[i] < a.foff_min) a.foff_min = a.foff[i];
         if (i == 0 || a.foff[i] > a.foff_max) a.foff_max = a.foff[i];
+    }
+    for (int g = 0; g < 2; ++g) { a.gt[g] = 0; a.gmin[g] = 0; a.gmax[g] = 0; }
+    a.gt[2] = 0;
+    if constexpr (ET<T>::IS_BF16) {
+        if (!dry && a.Cout > 64 && epi != 1 && conv_big_group_taps(a))
+            return epi == 2 ? launch_conv_big<T, 4, 2, 2, 2, 2, true>(a, stream) : launch_conv_big<T, 4, 2, 2, 2, 0, true>(a, stream);
     }
     const int Rv = a.Tv * a.V;
     // 256-row tiles read fewer fragments per MFMA; 128-row tiles waste less on the ragged last tile of a sample

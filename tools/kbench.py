@@ -3,7 +3,7 @@
     python tools/kbench.py gcn_fused:64:64 [--iters 20]
     rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY ... -- python3 tools/kbench.py gcn_fused:64:64 --iters 3
 
-Case syntax  name:Cin:Cout[:stride]  with T derived from the channel width (64 -> 300, 128 -> 150, 256 -> 75).
+Case syntax  name:Cin:Cout[:stride[:T]]  with T derived from the channel width (64 -> 300, 128 -> 150, 256 -> 75) unless given.
 Prints mean milliseconds per launch (events on the current stream).
 """
 import argparse
@@ -30,7 +30,7 @@ def make(case, dtype):
     parts = case.split(":")
     name, Cin, Cout = parts[0], int(parts[1]), int(parts[2])
     stride = int(parts[3]) if len(parts) > 3 else 1
-    Tin = {64: 300, 128: 150, 256: 75}.get(Cin, 300)
+    Tin = int(parts[4]) if len(parts) > 4 else {64: 300, 128: 150, 256: 75}.get(Cin, 300)
     if name in ("gcn_fused", "gcn_fused_add", "gcn_agrad", "gcn_wgrad"):
         x = act(Cin, Tin, dtype)
         adj = torch.rand((K, V, V), device=DEV) * 0.2

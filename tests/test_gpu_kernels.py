@@ -202,6 +202,8 @@ GCN_DIRECT = [
     ("openpose", "distance", True, 3, 64, 64, 301),
     ("ntu-rgb+d", "spatial", True, 2, 256, 80, 7),         # 8-wave workgroups with a ragged last column tile
     ("openpose", "spatial", False, 3, 128, 208, 9),
+    ("ntu-rgb+d", "spatial", False, 8, 256, 256, 150),     # weights-in-registers form: several batches of frames per workgroup
+    ("openpose", "uniform", True, 5, 128, 192, 131),       # a column group with spare waves, frame count not a multiple of the batch
 ]
 
 

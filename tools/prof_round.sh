@@ -16,7 +16,7 @@ KT=$(ls $O/kt/*/*kernel_trace.csv | head -1); python3 $R/tools/step_trace.py $KT
 python3 $R/tools/step_trace.py $KT 0 > $O/step_launch_summary_launch_by_launch.txt 2>&1
 python3 - $KT > $O/bench_bf16_dominant_kernel_dispatches.csv <<'PY'
 import csv, sys
-rows = [r for r in csv.DictReader(open(sys.argv[1])) if "conv_big_kernel<bf16, 4, 2, 2, 2, 1>" in r["Kernel_Name"]]
+rows = [r for r in csv.DictReader(open(sys.argv[1])) if "conv_big_kernel<bf16, 4, 2, 2, 2, 1," in r["Kernel_Name"]]
 print("start_ns,duration_us,grid,workgroup")
 for r in sorted(rows, key=lambda r: int(r["Start_Timestamp"])):
     print("%s,%.1f,%s,%s" % (r["Start_Timestamp"], (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3, r.get("Grid_Size", r.get("Grid_Size_X", "")), r.get("Workgroup_Size", r.get("Workgroup_Size_X", ""))))

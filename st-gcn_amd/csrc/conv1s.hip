@@ -202,3 +202,161 @@ int conv1s_try(const void* in, const void* w, void* out, const float* bias, doub
     default:  return Cout <= 128 ? launch_conv1s<16, 2>(a, stream) : -1;     // 64-column passes: two sets of 16 A fragments fill the registers
     }
 }
+
+// ------------------------------------------------------------------------------------------
+// Weight gradient of the same convolution:  dW[co][ci] = sum over virtual rows u of dout[orow(u)][co] * in[irow(u)][ci].
+// The tiled weight-gradient kernels give a workgroup one (64 co x 64 ci) pair, so every pair re-reads its rows; with
+// one tap the whole Cout x Cin result (256 x 128 or 128 x 64) fits the accumulators of ONE workgroup: wave
+// (wco, wci) owns TCO x TCI tiles of 32 x 32, the workgroup streams batches of 64 rows of both tensors through LDS
+// once (double-buffered, the next batch in registers while this one multiplies), and both MFMA operands come out of
+// the [row][channel] images through ds_read_b64_tr_b16, the contraction running over the rows.  One partial per
+// workgroup goes to the slab; the fixed-order slab reduction of the tiled kernels sums them.
+struct Conv1sWgArgs {
+    const void* in; const void* dout; float* slab;
+    int V, Tv, Tin, fs;
+    int nrows, nbatches;
+};
+
+template <int TCO, int WCO, int TCI, int WCI>
+__global__ __launch_bounds__(512) void conv1s_wgrad_kernel(Conv1sWgArgs a) {
+    static_assert(WCO * WCI == 8, "eight waves");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int COUT = 32 * TCO * WCO, CIN = 32 * TCI * WCI;
+    constexpr int DRS = COUT * 2 + 16, XRS = CIN * 2 + 16, RB = 64;
+    constexpr int DPP = COUT / 8, XPP = CIN / 8;          // 16-byte pieces per row
+    constexpr int ND = RB * DPP / 512, NX = RB * XPP / 512;
+    static_assert(ND >= 1 && NX >= 1, "a batch is at least one piece per thread");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int q4 = (lane & 15) >> 2, p4 = lane & 3, g1 = (lane >> 4) & 1;
+    const int wco = wave % WCO, wci = wave / WCO;
+    char* dimg = smem;                                    // [2][RB][DRS]
+    char* ximg = smem + 2 * RB * DRS;                     // [2][RB][XRS]
+    const int V = a.V, Rv = a.Tv * V;
+
+    f32x16 acc[TCO][TCI];
+#pragma unroll
+    for (int i = 0; i < TCO; ++i)
+#pragma unroll
+        for (int j = 0; j < TCI; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    i32x4 dreg[ND], xreg[NX];
+    auto load_batch = [&](int bi) {
+        const int u0 = bi * RB;
+#pragma unroll
+        for (int i = 0; i < ND; ++i) {
+            const int p = tid + 512 * i, row = p / DPP, seg = p - row * DPP;
+            const int u = u0 + row;
+            dreg[i] = zero16();
+            if (u < a.nrows) dreg[i] = *(const i32x4*)((const char*)a.dout + ((size_t)u * COUT + seg * 8) * 2);
+        }
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const int p = tid + 512 * i, row = p / XPP, seg = p - row * XPP;
+            const int u = u0 + row;
+            xreg[i] = zero16();
+            if (u < a.nrows) {
+                const int b = u / Rv, rem = u - b * Rv;
+                const int j = rem / V, v = rem - j * V;
+                const size_t irow = ((size_t)b * a.Tin + a.fs * j) * V + v;
+                xreg[i] = *(const i32x4*)((const char*)a.in + (irow * CIN + seg * 8) * 2);
+            }
+        }
+    };
+    auto commit = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < ND; ++i) {
+            const int p = tid + 512 * i, row = p / DPP, seg = p - row * DPP;
+            *(i32x4*)(dimg + ((size_t)buf * RB + row) * DRS + seg * 16) = dreg[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const int p = tid + 512 * i, row = p / XPP, seg = p - row * XPP;
+            *(i32x4*)(ximg + ((size_t)buf * RB + row) * XRS + seg * 16) = xreg[i];
+        }
+    };
+    typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
+    auto compute = [&](int buf) {
+        const char* di = dimg + (size_t)buf * RB * DRS;
+        const char* xi = ximg + (size_t)buf * RB * XRS;
+#pragma unroll
+        for (int s = 0; s < RB / 16; ++s) {
+            const int row = 16 * s + 8 * h + q4;
+            s16x8 af[TCO], bf[TCI];
+#pragma unroll
+            for (int t = 0; t < TCO; ++t) {
+                const int col = ((wco * TCO + t) * 32 + 16 * g1 + 4 * p4) * 2;
+                const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(di + row * DRS + col));
+                const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(di + (row + 4) * DRS + col));
+                af[t] = s16x8{a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+            }
+#pragma unroll
+            for (int t = 0; t < TCI; ++t) {
+                const int col = ((wci * TCI + t) * 32 + 16 * g1 + 4 * p4) * 2;
+                const s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(xi + row * XRS + col));
+                const s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(xi + (row + 4) * XRS + col));
+                bf[t] = s16x8{b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+            }
+#pragma unroll
+            for (int i = 0; i < TCO; ++i)
+#pragma unroll
+                for (int j = 0; j < TCI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    int bi = blockIdx.x;
+    if (bi < a.nbatches) { load_batch(bi); commit(0); }
+    lds_barrier();
+    for (int it = 0; bi < a.nbatches; ++it, bi += gridDim.x) {
+        const int nb = bi + gridDim.x;
+        if (nb < a.nbatches) load_batch(nb);
+        compute(it & 1);
+        if (nb < a.nbatches) commit((it + 1) & 1);
+        lds_barrier();
+    }
+
+    float* part = a.slab + (size_t)blockIdx.x * COUT * CIN;
+#pragma unroll
+    for (int i = 0; i < TCO; ++i)
+#pragma unroll
+        for (int j = 0; j < TCI; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = (wco * TCO + i) * 32 + acc_row(r, h), ci = (wci * TCI + j) * 32 + l31;
+                part[(size_t)co * CIN + ci] = acc[i][j][r];
+            }
+}
+
+template <int TCO, int WCO, int TCI, int WCI>
+static int launch_conv1s_wgrad(Conv1sWgArgs& a, void* ws, size_t ws_bytes, int* nparts, hipStream_t stream) {
+    constexpr int COUT = 32 * TCO * WCO, CIN = 32 * TCI * WCI;
+    const size_t lds = 2 * 64 * (size_t)(COUT * 2 + 16) + 2 * 64 * (size_t)(CIN * 2 + 16);
+    const size_t per_part = (size_t)COUT * CIN * sizeof(float);
+    int gx = min(stgcn_num_cus(), a.nbatches);
+    while (gx > 1 && (size_t)gx * per_part > ws_bytes) gx /= 2;
+    if ((size_t)gx * per_part > ws_bytes) return STGCN_ERR_WORKSPACE;
+    a.slab = (float*)ws;
+    auto kern = conv1s_wgrad_kernel<TCO, WCO, TCI, WCI>;
+    static std::atomic<uint64_t> lds_ok{0};
+    if (stgcn_allow_big_lds((const void*)kern, lds_ok) != STGCN_OK) return STGCN_ERR_LAUNCH;
+    hipLaunchKernelGGL(kern, dim3((unsigned)gx), dim3(512), lds, stream, a);
+    *nparts = gx;
+    return hipGetLastError() == hipSuccess ? STGCN_OK : STGCN_ERR_LAUNCH;
+}
+
+// Launches the partial sums; -1 when the shape is outside this kernel's domain.  On STGCN_OK *nparts partials
+// [Cout][Cin] (float32) lie at the start of the workspace for the caller's fixed-order reduction.
+int conv1s_wgrad_try(const void* in, const void* dout, int B, int Tin, int Tout, int V, int Cin, int Cout, int stride,
+                     void* ws, size_t ws_bytes, int* nparts, hipStream_t stream) {
+    if (stride < 1 || stride > 2 || V < 1 || B < 1 || Tin < 1 || Tout < 1 || (long long)(Tout - 1) * stride > Tin - 1) return -1;
+    const long long nrows = (long long)B * Tout * V;
+    if (nrows > (1ll << 30) || (long long)B * Tin * V > (1ll << 30)) return -1;
+    Conv1sWgArgs a;
+    a.in = in; a.dout = dout; a.slab = nullptr; a.V = V; a.Tv = Tout; a.Tin = Tin; a.fs = stride;
+    a.nrows = (int)nrows; a.nbatches = (int)((nrows + 63) / 64);
+    if (Cout == 256 && Cin == 128) return launch_conv1s_wgrad<2, 4, 2, 2>(a, ws, ws_bytes, nparts, stream);
+    if (Cout == 128 && Cin == 64) return launch_conv1s_wgrad<1, 4, 1, 2>(a, ws, ws_bytes, nparts, stream);
+    return -1;
+}

@@ -591,6 +591,10 @@ static int conv_wgrad_run(ConvWgradArgs& a, float* dW, size_t ws_bytes, hipStrea
     return hipGetLastError() == hipSuccess ? STGCN_OK : STGCN_ERR_LAUNCH;
 }
 
+// streaming path for the 1-tap convolution of the residual branch (conv1s.hip); -1 = shape not covered
+int conv1s_wgrad_try(const void* in, const void* dout, int B, int Tin, int Tout, int V, int Cin, int Cout, int stride,
+                     void* ws, size_t ws_bytes, int* nparts, hipStream_t stream);
+
 extern "C" int stgcn_conv_wgrad(int dtype, const void* in, const void* dout, float* dW,
                                 const float* pro_scale, const float* pro_shift,
                                 int B, int Tin, int Tout, int V, int Cin, int Cout,
@@ -603,6 +607,16 @@ extern "C" int stgcn_conv_wgrad(int dtype, const void* in, const void* dout, flo
     a.B = B; a.Tin = Tin; a.Tout = Tout; a.V = V; a.Cin = Cin; a.Cout = Cout;
     a.ntaps = ntaps; a.stride = stride; a.pad = pad; a.dil = dil;
     a.win_rows_max = 0; a.tiles_per_sample = 0; a.nseg = 0;
+    if (dtype == STGCN_BF16 && ntaps == 1 && pad == 0 && dil == 1 && !pro_scale) {
+        int nparts = 0;
+        const int rc = conv1s_wgrad_try(in, dout, B, Tin, Tout, V, Cin, Cout, stride, workspace, workspace_bytes, &nparts, (hipStream_t)stream);
+        if (rc == STGCN_OK) {
+            const size_t n = (size_t)Cout * Cin;
+            hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3(slab_sum_grid(n)), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, dW, nparts, 1, Cout, Cin);
+            return hipGetLastError() == hipSuccess ? STGCN_OK : STGCN_ERR_LAUNCH;
+        }
+        if (rc > 0) return rc;
+    }
     if (dtype == STGCN_BF16 && dil == 1 && pad == (ntaps - 1) / 2 && B > 0 && Tin > 0 &&
         Tout == (Tin - 1) / stride + 1) {
         const int rc = conv_wgrad_ring_try(in, dout, dW, pro_scale, pro_shift, B, Tin, Tout, V, Cin, Cout, ntaps, stride,

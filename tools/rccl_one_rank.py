@@ -27,6 +27,7 @@ def main():
     torch.cuda.set_device(dev)
     dist.init_process_group("nccl", device_id=dev)
     assert dist.get_world_size() == 1 and dist.get_backend() == "nccl"
+    print("RCCL_ONE_RANK_GROUP_UP", flush=True)         # from here on a failure is the trainer's, not the rendezvous'
 
     from oracle import stgcn_oracle as O
     import net.st_gcn as mod

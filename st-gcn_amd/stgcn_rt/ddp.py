@@ -277,7 +277,10 @@ class Trainer:
         self.bucketer.hooks_enabled = False
         try:
             torch.cuda.synchronize()
-            with torch.cuda.graph(g):
+            # thread_local: the capture restricts this thread only.  The process group's watchdog thread polls the
+            # events of earlier all-reduces with hipEventQuery; under the default (global) mode such a call from
+            # another thread during the capture is an error that the watchdog turns into an abort of the process.
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 loss = self._forward_backward(sx, sl)
                 self.flat.gather(range(len(self.flat.params)))
         except Exception as e:                # stay in this process: step launch by launch from now on

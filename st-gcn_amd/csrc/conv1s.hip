@@ -196,6 +196,7 @@ int conv1s_try(const void* in, const void* w, void* out, const float* bias, doub
     if (nrows > (1ll << 30) || (long long)B * max(Tin, Tout) * V > (1ll << 30)) return -1;     // row indices are ints
     a.nrows = (int)nrows; a.nblocks = (int)((nrows + 31) / 32);
     const bool wide = Cout % 128 == 0;
+    if (!wide && Cout > 128) return -1;                   // 64-column passes: the kernel unrolls two of them
     switch (Cin) {
     case 64:  return wide ? launch_conv1s<4, 4>(a, stream) : launch_conv1s<4, 2>(a, stream);
     case 128: return wide ? launch_conv1s<8, 4>(a, stream) : launch_conv1s<8, 2>(a, stream);

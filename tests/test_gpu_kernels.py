@@ -75,6 +75,7 @@ CONV_CASES = [
     (2, 128, 64, 21, 25, 1, 2, 0, False),
     (3, 256, 128, 30, 25, 1, 2, 0, False),
     (40, 64, 128, 299, 25, 1, 2, 0, False),
+    (2, 64, 192, 13, 25, 1, 2, 0, False),            # three 64-column passes: outside the streaming kernel's domain
     # stride-2 forward with its taps in two parity groups: a sample shorter than one tile's window, several tiles per sample
     (2, 128, 128, 9, 25, 9, 2, 4, True),
     (1, 256, 256, 150, 25, 9, 2, 4, True),

@@ -1149,8 +1149,10 @@ template <typename T>
 static int gcn_wgrad_run(GcnWgradArgs& a, float* dW, float* db, size_t ws_bytes, hipStream_t stream) {
     constexpr int ES = ET<T>::ES, KSTEP = ET<T>::KSTEP;
     if (a.Cin % KSTEP != 0 || a.Cin <= 0 || a.Cout % 8 != 0 || a.Cout <= 0 || a.K < 1 || a.K > GCN_KMAX || a.V < 1 || a.V > 32 || a.NF < 1) return STGCN_ERR_ARG;
-    const int cig = a.Cin >= 64 ? 64 : a.Cin;
-    if (a.Cin % cig != 0) return STGCN_ERR_ARG;
+    // input channels per workgroup: the widest group of whole k-steps, at most 64 channels, that divides Cin
+    // (64 for the usual widths; 48 for 96 channels, 16 for 80)
+    int cig = a.Cin >= 64 ? 64 : a.Cin;
+    while (a.Cin % cig != 0) cig -= KSTEP;
     a.cig = cig;
     const int drs = 32 * ES + 16, xrs = cig * ES + 16;
     const size_t tabb = ET<T>::IS_BF16 ? (size_t)a.K * 2 * 64 * 16 : (size_t)a.K * 32 * 32 * 4;

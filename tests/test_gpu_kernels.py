@@ -205,6 +205,8 @@ GCN_DIRECT = [
     ("openpose", "spatial", False, 3, 128, 208, 9),
     ("ntu-rgb+d", "spatial", False, 8, 256, 256, 150),     # weights-in-registers form: several batches of frames per workgroup
     ("openpose", "uniform", True, 5, 128, 192, 131),       # a column group with spare waves, frame count not a multiple of the batch
+    ("ntu-rgb+d", "spatial", True, 2, 96, 64, 7),          # input widths above 64 that are no multiple of 64: the weight
+    ("openpose", "distance", False, 1, 80, 48, 9),         # gradient splits them into groups of 48 / 16 channels
 ]
 
 

@@ -1,8 +1,8 @@
 """Random-shape sweep of the temporal-convolution entry points (forward with statistics, transposed form, weight
-gradient) in bf16 against the CPU oracle: channel widths, strides, tap counts, joint counts and frame counts drawn at
+gradient) (bf16, or f32 on request) against the CPU oracle: channel widths, strides, tap counts, joint counts and frame counts drawn at
 random, so that every dispatch boundary between the convolution kernels is crossed many times.
 
-    python tools/fuzz_conv.py [cases] [seed]
+    python tools/fuzz_conv.py [cases] [seed] [bf16|f32]
 """
 import os
 import random
@@ -19,8 +19,8 @@ from stgcn_rt import lib as L                  # noqa: E402
 from stgcn_rt import ops as R                  # noqa: E402
 
 DEV = "cuda:0"
-dt = torch.bfloat16
-TOL = 2e-2
+dt = torch.float32 if (len(sys.argv) > 3 and sys.argv[3] == "f32") else torch.bfloat16
+TOL = 1e-4 if dt == torch.float32 else 2e-2
 
 
 def t64(shape, tag, lo=-1.0, hi=1.0):

@@ -337,13 +337,26 @@ __global__ __launch_bounds__(512) void conv_wgrad_ring_kernel(ConvWgradRingArgs 
         if (tile_beg >= tile_end) continue;
         const uint16_t* inb = (const uint16_t*)a.in + (size_t)b * Rin * Cin + ci0;
         const uint16_t* dob = (const uint16_t*)a.dout + (size_t)b * Rout * Cout + co0;
-        i32x4 pf[4];
+        // Rows in flight: pf holds input rows on their way to the ring, pd the next dout tile.  Stride 2 (8 k-steps a
+        // tile: half a tile is shorter than a trip to memory) fetches both at the top of a tile, from clamped addresses
+        // on every path (rows outside the sample become zeros when they are committed): loads behind a branch are
+        // "maybe issued" to the compiler's wait-count pass, and its wait for pd in the middle of the tile would then
+        // also be a wait for pf, issued just after it.  Stride 1 has no registers left for a second set (it spills
+        // with one, and runs 6-8 % slower): there pd IS pf, the dout tile travels in the first half of a tile and the
+        // input rows in the second.
+        constexpr bool TWO_SETS = STRIDE == 2;
+        i32x4 pf[4], pd2[TWO_SETS ? DPASS : 1];
+        i32x4* const pd = TWO_SETS ? pd2 : pf;
         auto fetch_in = [&](int p_first) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int p = p_first + srow + 64 * i;
-                pf[i] = zero16();
-                if (p >= 0 && p < Rin) pf[i] = *(const i32x4*)(inb + (size_t)p * Cin + sseg * 8);
+                if constexpr (TWO_SETS) {
+                    pf[i] = *(const i32x4*)(inb + (size_t)min(max(p, 0), Rin - 1) * Cin + sseg * 8);
+                } else {
+                    pf[i] = zero16();
+                    if (p >= 0 && p < Rin) pf[i] = *(const i32x4*)(inb + (size_t)p * Cin + sseg * 8);
+                }
             }
         };
         auto commit_in = [&](int p_first, int nrows) {
@@ -354,6 +367,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_ring_kernel(ConvWgradRingArgs 
                 if (rel < nrows) {
                     i32x4 v = pf[i];
                     if (p >= 0 && p < Rin) v = transform(v);
+                    else if (TWO_SETS) v = zero16();
                     const int slot = p & 511;
                     const int off = slot * RS + ((sseg * 16) ^ swz(slot));
                     *(i32x4*)(ring + off) = v;
@@ -361,19 +375,28 @@ __global__ __launch_bounds__(512) void conv_wgrad_ring_kernel(ConvWgradRingArgs 
                 }
             }
         };
+        const int dseg = co_ok ? sseg * 8 : 0;
         auto fetch_do = [&](int p_first) {
 #pragma unroll
             for (int i = 0; i < DPASS; ++i) {
                 const int rel = srow + 64 * i;
                 const int p = p_first + rel;
-                pf[i] = zero16();
-                if (rel < tile_rows && p < Rout && co_ok) pf[i] = *(const i32x4*)(dob + (size_t)p * Cout + sseg * 8);
+                if constexpr (TWO_SETS) {
+                    pd[i] = *(const i32x4*)(dob + (size_t)min(p, Rout - 1) * Cout + dseg);
+                } else {
+                    pd[i] = zero16();
+                    if (rel < tile_rows && p < Rout && co_ok) pd[i] = *(const i32x4*)(dob + (size_t)p * Cout + sseg * 8);
+                }
             }
         };
-        auto commit_do = [&](int buf) {
+        auto commit_do = [&](int buf, int p_first) {
 #pragma unroll
-            for (int i = 0; i < DPASS; ++i)
-                *(i32x4*)(dt + (size_t)buf * DROWS * RS + (srow + 64 * i) * RS + ((sseg * 16) ^ swz_d(srow))) = pf[i];
+            for (int i = 0; i < DPASS; ++i) {
+                const int rel = srow + 64 * i;
+                i32x4 v = pd[i];
+                if (TWO_SETS && !(rel < tile_rows && p_first + rel < Rout && co_ok)) v = zero16();
+                *(i32x4*)(dt + (size_t)buf * DROWS * RS + rel * RS + ((sseg * 16) ^ swz_d(srow))) = v;
+            }
         };
 
         int p0 = tile_beg * tile_rows;                    // first output row of the tile
@@ -385,7 +408,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_ring_kernel(ConvWgradRingArgs 
                 commit_in(first + base, span - base);
             }
             fetch_do(p0);
-            commit_do(0);
+            commit_do(0, p0);
         }
         int cur = 0;
         // stride 1: ring byte offset of this lane's first operand row of the coming k-step, per tap
@@ -402,7 +425,10 @@ __global__ __launch_bounds__(512) void conv_wgrad_ring_kernel(ConvWgradRingArgs 
             const int first = STRIDE * p0 - half * V;     // first input row of this tile's span
             const int pnew = first + span;                // first input row the next tile adds
             lds_barrier();                              // ring and dt[cur] visible
-            if (more) fetch_do(p0 + tile_rows);
+            if (more) {
+                fetch_do(p0 + tile_rows);
+                if constexpr (TWO_SETS) fetch_in(pnew);   // a whole tile's arithmetic to land, half of one for pd
+            }
             const char* dcur = dt + (size_t)cur * DROWS * RS;
             // Fragment reads run one MFMA ahead: the tap t+1 operand (or the next k-step's dout fragment and
             // tap-0 operand) is requested before the tap t MFMA issues, so the LDS latency hides under the MFMA pipe.
@@ -458,8 +484,8 @@ __global__ __launch_bounds__(512) void conv_wgrad_ring_kernel(ConvWgradRingArgs 
                 }
                 af = afn;
                 if (i == KW / 2 - 1 && more) {
-                    commit_do(cur ^ 1);                   // last read a tile ago: every wave has passed a barrier since
-                    fetch_in(pnew);
+                    commit_do(cur ^ 1, p0 + tile_rows);   // last read a tile ago: every wave has passed a barrier since
+                    if constexpr (!TWO_SETS) fetch_in(pnew);
                 }
             }
             lds_barrier();                              // every wave is done reading the ring

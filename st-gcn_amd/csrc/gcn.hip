@@ -94,8 +94,12 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : (NA >= 1 && NA <= 4 && (!A
     constexpr int VEC = ET<T>::VEC;
     constexpr int NAP = NA == 0 ? 1 : (NA < 16 ? NA : 16);     // fragments held per pass
     constexpr int NPASS = NA == 0 ? 0 : (NA + 15) / 16;
-    constexpr bool PF = NPASS == 1 && NA <= 8;                  // prefetch the next frame (register budget)
+    constexpr bool PF = NPASS == 1 && NA <= 8;                  // prefetch the next frame (register budget; at 256
+                                                                // channels a second set measured no gain without an addend)
     constexpr bool ONCE = NPASS == 1 && !PF;                    // fragments loaded once per frame, no prefetch
+    // frames fetched ahead: two where a third register set does not cost a resident workgroup (with an addend it
+    // would; at 128 input channels two measured 8 % slower than one)
+    constexpr int DEPTH = (PF && ET<T>::IS_BF16 && NA <= 4 && !ADD) ? 2 : 1;
     constexpr int NADD = ET<T>::IS_BF16 ? 4 : 8;                // addend pieces prefetched per lane (covers V * NC / VEC <= 64 * NADD)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5;
@@ -145,14 +149,17 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : (NA >= 1 && NA <= 4 && (!A
     const int brow = min(l31, V - 1);            // rows >= V duplicate the last joint; adj zeroes them
     auto frame_ptr = [&](int f) { return (const char*)a.in + (((size_t)f * V + brow) * Cin) * ES + h * 16; };
 
-    auto process = [&](int f, i32x4 (&cur)[NAP], i32x4 (&nxt)[NAP], int fnext) {
+    // cur: this frame's fragments; pre: the register set that takes the fragments of frame fpre (DEPTH frames ahead);
+    // nxt: the set of the next frame (pre itself at depth 1)
+    auto process = [&](int f, i32x4 (&cur)[NAP], i32x4 (&pre)[NAP], int fpre, i32x4 (&nxt)[NAP]) {
         const char* ap = frame_ptr(f);
         if constexpr (PF) {
-            if (fnext < NF) {
-                const char* np = frame_ptr(fnext);
+            // Issued on every path (past the last frame: the last frame again).  Behind a branch the loads would be
+            // "maybe issued" to the compiler's wait-count pass, which then waits for the CURRENT fragments as if they
+            // were the youngest loads in flight -- with the prefetch in flight that is a wait for the prefetch.
+            const char* np = frame_ptr(min(fpre, NF - 1));
 #pragma unroll
-                for (int s = 0; s < NAP; ++s) nxt[s] = *(const i32x4*)(np + s * 32);
-            }
+            for (int s = 0; s < NAP; ++s) pre[s] = *(const i32x4*)(np + s * 32);
         }
         if constexpr (ONCE) {
 #pragma unroll
@@ -161,16 +168,15 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : (NA >= 1 && NA <= 4 && (!A
         i32x4 addv[ADD ? NADD : 1];
         uint32_t addm[ADD ? NADD : 1];           // keep bits of the addend pieces (all ones without a mask)
         if (add_pf) {
+            // branch-free for the same reason: lanes without a piece read a valid one and never use it
+            const int esafe = col_ok ? eseg * VEC : 0;
 #pragma unroll
             for (int i = 0; i < NADD; ++i) {
-                const int p = lane + 64 * i;
-                addv[i] = zero16();
+                const int p = min(lane + 64 * i, npieces - 1);
+                const size_t o = ((size_t)f * V + (p >> pshift)) * Nout + nbase + esafe;
+                addv[i] = *(const i32x4*)((const T*)a.add + o);
                 addm[i] = 0xFFu;
-                if (p < npieces && col_ok) {
-                    const size_t o = ((size_t)f * V + (p >> pshift)) * Nout + nbase + eseg * VEC;
-                    addv[i] = *(const i32x4*)((const T*)a.add + o);
-                    if (a.add_mask) addm[i] = a.add_mask[o / VEC];
-                }
+                if (a.add_mask) addm[i] = a.add_mask[o / VEC];
             }
         }
         for (int nt = 0; nt < NTW; ++nt) {
@@ -221,6 +227,13 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : (NA >= 1 && NA <= 4 && (!A
             }
         }
         __builtin_amdgcn_wave_barrier();
+        if constexpr (PF) {
+            // The one wait for the prefetch, a frame's arithmetic after its issue and BEFORE this frame's stores: the
+            // next frame then starts on fragments the compiler knows to be complete, and no wait for them is also a
+            // wait for stores issued just before.
+#pragma unroll
+            for (int s = 0; s < NAP; ++s) asm volatile("" : "+v"(nxt[s]));
+        }
         // store phase: 16-byte pieces, whole channel rows coalesced; optional addend and statistics
         auto emit = [&](int p, bool have, i32x4 addval, uint32_t addbits) {
             const int row = p >> pshift;
@@ -260,21 +273,40 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : (NA >= 1 && NA <= 4 && (!A
     {
         const int fstep = gridDim.x * NWV;
         int f = blockIdx.x * NWV + wave;
-        i32x4 fa[NAP], fb[NAP];
+        i32x4 fa[NAP], fb[NAP], fc[NAP];
         if constexpr (PF) {
             if (f < NF) {
                 const char* ap = frame_ptr(f);
 #pragma unroll
                 for (int s = 0; s < NAP; ++s) fa[s] = *(const i32x4*)(ap + s * 32);
+                if constexpr (DEPTH == 2) {
+                    const char* bp = frame_ptr(min(f + fstep, NF - 1));
+#pragma unroll
+                    for (int s = 0; s < NAP; ++s) fb[s] = *(const i32x4*)(bp + s * 32);
+                }
             }
+            // complete before the loop, as every later frame's fragments are when its turn comes (see process)
+#pragma unroll
+            for (int s = 0; s < NAP; ++s) asm volatile("" : "+v"(fa[s]));
         }
         while (f < NF) {
-            process(f, fa, fb, f + fstep);
-            f += fstep;
-            if (f >= NF) break;
-            if constexpr (PF) process(f, fb, fa, f + fstep);
-            else process(f, fa, fb, f + fstep);
-            f += fstep;
+            if constexpr (DEPTH == 2) {
+                process(f, fa, fc, f + 2 * fstep, fb);
+                f += fstep;
+                if (f >= NF) break;
+                process(f, fb, fa, f + 2 * fstep, fc);
+                f += fstep;
+                if (f >= NF) break;
+                process(f, fc, fb, f + 2 * fstep, fa);
+                f += fstep;
+            } else {
+                process(f, fa, fb, f + fstep, fb);
+                f += fstep;
+                if (f >= NF) break;
+                if constexpr (PF) process(f, fb, fa, f + fstep, fa);
+                else process(f, fa, fb, f + fstep, fb);
+                f += fstep;
+            }
         }
     }
     if (a.stats) {

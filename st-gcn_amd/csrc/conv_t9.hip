@@ -202,6 +202,11 @@ __global__ __launch_bounds__(T9_NT) void conv_t9_kernel(ConvT9Args a) {
             }
         }
         lds_barrier();                                    // every wave is done reading the window
+        // The one wait for the rows fetched at the top of the tile, HERE, a whole MFMA phase after their issue and
+        // before the epilogue's stores: the commit at the end of the tile then needs none, and a wait placed there
+        // by the compiler would also be a wait for the stores issued just before it (waits retire in issue order).
+#pragma unroll
+        for (int i = 0; i < NPF; ++i) asm volatile("" : "+v"(pf[i]));
 
         // accumulators (+bias) -> bf16 -> dead ring slots (those of the rows the next tile brings in)
 #pragma unroll

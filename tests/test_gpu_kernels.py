@@ -269,10 +269,14 @@ def fenced(t, cl=False):
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
 @pytest.mark.parametrize("lay,strat,B,Cin,Cout,T", [("openpose", "uniform", 1, 16, 8, 5), ("ntu-rgb+d", "spatial", 2, 48, 24, 3),
-                                                    ("ntu-rgb+d", "spatial", 1, 32, 80, 4), ("openpose", "distance", 1, 256, 40, 2)])
+                                                    ("ntu-rgb+d", "spatial", 1, 32, 80, 4), ("openpose", "distance", 1, 256, 40, 2),
+                                                    ("ntu-rgb+d", "spatial", 1, 64, 64, 1), ("ntu-rgb+d", "spatial", 1, 64, 64, 3),
+                                                    ("openpose", "spatial", 1, 128, 128, 2), ("ntu-rgb+d", "spatial", 3, 64, 128, 23)])
 def test_gcn_kernels_stay_inside_their_inputs(rt, lay, strat, B, Cin, Cout, T, dtype):
     """Channel counts that are multiples of one k-step but not of a 32-column tile, every input fenced with NaN:
-    results finite and equal to the oracle's (a ragged tile's spare columns meet zero weights -- they must not be read)."""
+    results finite and equal to the oracle's (a ragged tile's spare columns meet zero weights -- they must not be read).
+    The 64- and 128-channel cases with one to three frames are for the frame prefetch, which runs one or two frames
+    ahead of a wave's last frame and must re-read a frame of the tensor, not what lies behind it."""
     if dtype == torch.bfloat16 and Cout % 16:
         Cout += 8                                # the gradient kernels contract over whole k-steps of Cout (16 in bf16)
     A0 = O.build_graph(lay, strat)["A"]
@@ -295,6 +299,9 @@ def test_gcn_kernels_stay_inside_their_inputs(rt, lay, strat, B, Cin, Cout, T, d
     stats = torch.zeros(2 * Cout, dtype=torch.float64, device=DEV)
     got = dict(y=(rt.gcn_fused(xd, wp, Ad, Cout, bias=bd, stats=stats, adj_t=True), y),
                dx=(rt.gcn_fused(dyd, wt, Ad, Cin), dx))
+    if Cin % (16 // xd.element_size()) == 0:
+        addt = q(t64((B, Cin, T, V), 66), dtype)
+        got["dx_add"] = (rt.gcn_fused(dyd, wt, Ad, Cin, add=fenced(to_dev(addt, dtype), cl=True)), dx + addt)
     dWk, dbk = rt.gcn_wgrad(xd, dyd, Ad)
     got.update(dW=(dWk.reshape(K * Cout, Cin), dW), db=(dbk, db), dA=(rt.gcn_agrad(xd, wp, bd, dyd), dA),
                dA_nobias=(rt.gcn_agrad(xd, wp, None, dyd), O.gcn_backward(x, Aq, W, None, dy)[3]))
@@ -307,7 +314,10 @@ def test_gcn_kernels_stay_inside_their_inputs(rt, lay, strat, B, Cin, Cout, T, d
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
 @pytest.mark.parametrize("case", [(1, 64, 8, 7, 18, 3, 1, 1, 1), (2, 64, 24, 9, 25, 9, 2, 4, 1), (1, 128, 40, 6, 25, 1, 1, 0, 1),
                                   (1, 64, 64, 11, 18, 3, 2, 2, 2), (2, 64, 64, 10, 25, 5, 3, 0, 1),
-                                  (2, 64, 128, 13, 25, 1, 2, 0, 1), (1, 128, 64, 8, 18, 1, 2, 0, 1)], ids=lambda c: "x".join(map(str, c)))
+                                  (2, 64, 128, 13, 25, 1, 2, 0, 1), (1, 128, 64, 8, 18, 1, 2, 0, 1),
+                                  # 9 taps, stride 2, several tiles per sample with a ragged last one: the weight gradient's
+                                  # rows in flight are fetched from clamped addresses
+                                  (2, 64, 64, 41, 25, 9, 2, 4, 1), (1, 128, 128, 30, 18, 9, 2, 4, 1)], ids=lambda c: "x".join(map(str, c)))
 def test_conv_kernels_stay_inside_their_inputs(rt, case, dtype):
     """The temporal convolution at narrow / ragged output widths, strides up to 3 and dilation, inputs fenced with NaN."""
     B, Cin, Cout, T, V, kt, stride, pad, dil = case

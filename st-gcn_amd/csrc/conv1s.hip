@@ -73,13 +73,15 @@ __global__ __launch_bounds__(C1_WAVES * 64) void conv1s_kernel(Conv1sArgs a) {
             fill = min(a.nfill, a.Tout - 1 - a.os * j);
         }
     };
+    // Lanes without a row (past the last block) read row 0 and their results are never stored: the loads are issued
+    // on every path, so that the compiler's wait counts see exactly what is in flight (see the loop below).
     auto load_a = [&](i32x4 (&af)[KS], int irow) {
         const char* src = (const char*)a.in + ((size_t)max(irow, 0) * CIN + h * 8) * 2;
 #pragma unroll
-        for (int s = 0; s < KS; ++s) af[s] = irow >= 0 ? *(const i32x4*)(src + s * 32) : zero16();
+        for (int s = 0; s < KS; ++s) af[s] = *(const i32x4*)(src + s * 32);
     };
     const int piece = lane % P, prow = lane / P;
-    auto block = [&](const i32x4 (&af)[KS], int orow, int fill) {
+    auto block = [&](const i32x4 (&af)[KS], i32x4 (&nxt)[KS], int orow, int fill) {
         if (h == 0) { orow_l[l31] = orow; fill_l[l31] = fill; }
 #pragma unroll
         for (int p = 0; p < 2; ++p) {                      // at most two passes (Cout <= 256); unrolled: s1/s2 stay in registers
@@ -100,6 +102,12 @@ __global__ __launch_bounds__(C1_WAVES * 64) void conv1s_kernel(Conv1sArgs a) {
                     const i32x4 bf = *(const i32x4*)(wb + (size_t)n * 32 * WRS + s * 32);
                     mma_step<bf16>(acc[n], af[s], bf);
                 }
+            if (p == 0) {
+                // the one wait for the next block's fragments: behind this block's first MFMA run and before its
+                // stores, so that no later wait for them is also a wait for those stores
+#pragma unroll
+                for (int s = 0; s < KS; ++s) asm volatile("" : "+v"(nxt[s]));
+            }
 #pragma unroll
             for (int n = 0; n < NT; ++n)
 #pragma unroll
@@ -128,15 +136,20 @@ __global__ __launch_bounds__(C1_WAVES * 64) void conv1s_kernel(Conv1sArgs a) {
     i32x4 af0[KS], af1[KS];
     int ir, or0, fl0, or1, fl1;
     int blk = gw;
-    if (blk < a.nblocks) { geo(blk, ir, or0, fl0); load_a(af0, ir); }
+    geo(blk, ir, or0, fl0);                                // geo gives "no row" (-1) to every lane of a block past the end
+    load_a(af0, ir);
+#pragma unroll
+    for (int s = 0; s < KS; ++s) asm volatile("" : "+v"(af0[s]));
     while (blk < a.nblocks) {
         const int b1 = blk + gstep;
-        if (b1 < a.nblocks) { geo(b1, ir, or1, fl1); load_a(af1, ir); }
-        block(af0, or0, fl0);
+        geo(b1, ir, or1, fl1);
+        load_a(af1, ir);
+        block(af0, af1, or0, fl0);
         if (b1 >= a.nblocks) break;
         const int b2 = b1 + gstep;
-        if (b2 < a.nblocks) { geo(b2, ir, or0, fl0); load_a(af0, ir); }
-        block(af1, or1, fl1);
+        geo(b2, ir, or0, fl0);
+        load_a(af0, ir);
+        block(af1, af0, or1, fl1);
         blk = b2;
     }
 

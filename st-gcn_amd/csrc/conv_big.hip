@@ -353,6 +353,13 @@ __global__ __launch_bounds__(WR * WC * 64) void conv_big_kernel(ConvBigArgs a) {
                         if (rr >= 0 && a.aux) av[i] = *(const i32x4*)(auxb + (size_t)rr * Cout);
                     }
                 }
+                if constexpr (EPI != 0) {
+                    // ONE wait for the group's auxiliary rows, before its first store: the loads sit behind branches, so
+                    // the compiler would wait for each row with vmcnt(0) -- from the second row on that is also a wait
+                    // for the store of the row before (waits retire in issue order), one trip to memory per row
+#pragma unroll
+                    for (int i = 0; i < EG; ++i) asm volatile("" : "+v"(av[i]));
+                }
 #pragma unroll
                 for (int i = 0; i < EG; ++i) {
                     if (rrow[i] >= 0) {

@@ -207,6 +207,10 @@ __global__ __launch_bounds__(T9_NT) void conv_t9_kernel(ConvT9Args a) {
         // by the compiler would also be a wait for the stores issued just before it (waits retire in issue order).
 #pragma unroll
         for (int i = 0; i < NPF; ++i) asm volatile("" : "+v"(pf[i]));
+        if constexpr (EPI != 0) {                         // the auxiliary rows as well: one wait, not one per row behind the row before's store
+#pragma unroll
+            for (int i = 0; i < NPF; ++i) asm volatile("" : "+v"(av[i]));
+        }
 
         // accumulators (+bias) -> bf16 -> dead ring slots (those of the rows the next tile brings in)
 #pragma unroll

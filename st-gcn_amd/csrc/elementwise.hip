@@ -351,23 +351,38 @@ __global__ __launch_bounds__(NT) void block_out_bwd_apply_kernel(BlockOutBwdArgs
     if (m.active) {
         // k*(gd - m1 - ohat*m2) with ohat = (o - mean)*rstd, folded to three constants per channel:
         //   k*gd + qa*o + qb,  qa = -k*m2*rstd,  qb = -k*m1 - qa*mean
+        // every per-channel load first (from a valid address on every path), then the arithmetic: channel by channel
+        // each channel's loads would wait behind the previous channel's divisions -- eight trips to memory in a row
         float k2[VEC], qa2[VEC], qb2[VEC], kr[VEC], qar[VEC], qbr[VEC];
+        float rs2[VEC], mn2[VEC], rsr[VEC], mnr[VEC];
+        double s2a[VEC], s2b[VEC], sra[VEC], srb[VEC];
+        const double* st2 = a.training ? a.stats2 : (const double*)a.mean2;      // not read when not training
+        const double* str = (HAS_R && a.training) ? a.statsr : (const double*)a.mean2;
+        const int cs = a.training ? a.C : 0;
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
             const int c = m.cv * VEC + j;
-            const float rs2 = a.rstd2[c];
-            k2[j] = a.gamma2[c] * rs2;
-            const float m1 = a.training ? (float)(a.stats2[c] / a.count) : 0.f;
-            const float m2 = a.training ? (float)(a.stats2[a.C + c] / a.count) : 0.f;
-            qa2[j] = -k2[j] * m2 * rs2;
-            qb2[j] = -k2[j] * m1 - qa2[j] * a.mean2[c];
+            const int cd = a.training ? c : 0;
+            rs2[j] = a.rstd2[c]; k2[j] = a.gamma2[c]; mn2[j] = a.mean2[c];
+            s2a[j] = st2[cd]; s2b[j] = st2[cs + cd];
             if constexpr (HAS_R) {
-                const float rsr = a.rstdr[c];
-                kr[j] = a.gammar[c] * rsr;
-                const float n1 = a.training ? (float)(a.statsr[c] / a.count) : 0.f;
-                const float n2 = a.training ? (float)(a.statsr[a.C + c] / a.count) : 0.f;
-                qar[j] = -kr[j] * n2 * rsr;
-                qbr[j] = -kr[j] * n1 - qar[j] * a.meanr[c];
+                rsr[j] = a.rstdr[c]; kr[j] = a.gammar[c]; mnr[j] = a.meanr[c];
+                sra[j] = str[cd]; srb[j] = str[cs + cd];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            k2[j] *= rs2[j];
+            const float m1 = a.training ? (float)(s2a[j] / a.count) : 0.f;
+            const float m2 = a.training ? (float)(s2b[j] / a.count) : 0.f;
+            qa2[j] = -k2[j] * m2 * rs2[j];
+            qb2[j] = -k2[j] * m1 - qa2[j] * mn2[j];
+            if constexpr (HAS_R) {
+                kr[j] *= rsr[j];
+                const float n1 = a.training ? (float)(sra[j] / a.count) : 0.f;
+                const float n2 = a.training ? (float)(srb[j] / a.count) : 0.f;
+                qar[j] = -kr[j] * n2 * rsr[j];
+                qbr[j] = -kr[j] * n1 - qar[j] * mnr[j];
             } else { kr[j] = qar[j] = qbr[j] = 0.f; }
         }
         constexpr bool want_r = HAS_R;
@@ -495,13 +510,25 @@ __global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(BnBwdArgs a) {
         }
     }
     if (!m.active) return;
+    // Per-channel constants: every load first (from a valid address on every path), then the arithmetic.  Written
+    // channel by channel -- load, branch on `training`, divide -- the compiler keeps each channel's loads behind the
+    // previous channel's wait: eight trips to memory in a row before the first row moves.
     float mu[VEC], rs[VEC], kk[VEC], m1[VEC], m2[VEC];
+    double sa[VEC], sb[VEC];
+    const double* st = a.training ? a.stats : (const double*)a.mean;     // not read when not training: any valid address
+    const int cs = a.training ? a.C : 0;
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
         const int c = m.cv * VEC + j;
-        mu[j] = a.mean[c]; rs[j] = a.rstd[c]; kk[j] = a.gamma[c] * rs[j];
-        m1[j] = a.training ? (float)(a.stats[c] / a.count) : 0.f;
-        m2[j] = a.training ? (float)(a.stats[a.C + c] / a.count) : 0.f;
+        mu[j] = a.mean[c]; rs[j] = a.rstd[c]; kk[j] = a.gamma[c];
+        const int cd = a.training ? c : 0;
+        sa[j] = st[cd]; sb[j] = st[cs + cd];
+    }
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+        kk[j] *= rs[j];
+        m1[j] = a.training ? (float)(sa[j] / a.count) : 0.f;
+        m2[j] = a.training ? (float)(sb[j] / a.count) : 0.f;
     }
     for (size_t row = (size_t)blockIdx.x * m.rpi + m.rl; row < a.rows; row += (size_t)gridDim.x * m.rpi) {
         const size_t off = row * a.C + m.cv * VEC;

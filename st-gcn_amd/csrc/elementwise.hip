@@ -875,10 +875,11 @@ __global__ void head_fc_bwd_kernel(const float* __restrict__ dlog, const float* 
         for (; n + 8 <= N; n += 8) {
             float pm[8], dl[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                pm[u] = 0.f;
-                for (int mm = 0; mm < M; ++mm) pm[u] += pooled[((size_t)(n + u) * M + mm) * C + c];
-                dl[u] = dlog[(size_t)(n + u) * ncls + j];
+            for (int u = 0; u < 8; ++u) { pm[u] = 0.f; dl[u] = dlog[(size_t)(n + u) * ncls + j]; }
+            // persons outside, samples inside: eight loads in flight per person (each sample's own sum keeps its order)
+            for (int mm = 0; mm < M; ++mm) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) pm[u] += pooled[((size_t)(n + u) * M + mm) * C + c];
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) s = fmaf(dl[u], pm[u] / (float)M, s);

@@ -17,6 +17,18 @@ def downsample(data, step, random_sample=True, rng=None):
     return data[:, begin::step, :, :]
 
 
+def temporal_slice(data, step):
+    """Groups of `step` consecutive frames folded into the person axis: (C, T, V, M) -> (C, T // step, V, step * M)
+    with out[c, g, v, s * M + m] = data[c, g * step + s, v, m] (tools.py:11-15).  T must be a multiple of `step`.
+    The reference's own version divides with `/` and cannot run under Python 3, so no fixture of it exists: this
+    function is checked by hand-computed cases only."""
+    C, T, V, M = data.shape
+    if T % step != 0:
+        raise ValueError("temporal_slice: %d frames are no multiple of step %d" % (T, step))
+    G = T // step
+    return data.reshape(C, G, step, V, M).transpose((0, 1, 3, 2, 4)).reshape(C, G, V, step * M)
+
+
 def mean_subtractor(data, mean):
     """Subtract `mean` from every frame up to the last non-empty one, in place (tools.py:18-28).  mean == 0
     returns None, as the reference does."""

@@ -92,6 +92,17 @@ class Model(nn.Module):
         s = bn.weight.detach().float() * torch.rsqrt(bn.running_var.float() + bn.eps)
         return s.contiguous(), (bn.bias.detach().float() - bn.running_mean.float() * s).contiguous()
 
+    def invalidate_plan(self):
+        """Forget the folded inference parameters.  Called by everything that rewrites parameters or running
+        statistics through raw pointers -- the fused SGD kernel, the BatchNorm kernels of a training forward, a replayed
+        HIP graph of either -- because such writes never advance a tensor's `_version`, which is all the plan's key can
+        see of a tensor's contents."""
+        self._plan = None
+
+    def train(self, mode=True):
+        self._plan = None                               # every train <-> eval transition starts from a fresh plan
+        return super().train(mode)
+
     def _eval_plan(self, dtype, device):
         tensors = list(self.parameters()) + list(self.buffers())
         key = (dtype, device, tuple((t.data_ptr(), t._version) for t in tensors))
@@ -163,6 +174,7 @@ class Model(nn.Module):
         N, C, T, V, M = x.size()
         dtype = self.compute_dtype
         bn = self.data_bn
+        self._plan = None                               # this pass may rewrite running statistics through raw pointers
         # Train / eval follows each sub-module's own flag, as in the reference where every nn.BatchNorm / nn.Dropout
         # consults its own .training (a model in train mode with its BatchNorms frozen by .eval() is a common
         # fine-tuning set-up).

@@ -58,6 +58,7 @@ class FlatParams:
         if order is not None:
             params = order(params)
         self.params = params
+        self.module = module
         self.sizes = [p.numel() for p in params]
         self.offsets = [0]
         for n in self.sizes:
@@ -220,6 +221,10 @@ class SGD:
         P.sgd_step(self.flat.flat, self.flat.grad, self.flat.mom, self.lr, self.momentum, self.weight_decay,
                    self.nesterov, self.flat.steps == 0, grad_scale)
         self.flat.steps += 1
+        # the kernel wrote the parameters through raw pointers: nothing derived from their old values may survive
+        drop = getattr(self.flat.module, "invalidate_plan", None)
+        if drop is not None:
+            drop()
 
 
 def adjust_lr(base_lr, epoch, steps):
@@ -251,6 +256,7 @@ class Trainer:
         self.use_graph = bool(graph)
         self._graphs = {}                     # (data shape, label shape) -> (graph, static data, static label, static loss)
         self._eager_steps = 0
+        self._grads_bound = False             # whether every p.grad is the parameter's slice of the flat gradient
 
     def broadcast_from_rank0(self):
         if self.bucketer.distributed:
@@ -322,8 +328,15 @@ class Trainer:
                 if label.data_ptr() != sl.data_ptr():
                     sl.copy_(label, non_blocking=True)
                 g.replay()
+                if not self._grads_bound:
+                    # the replay leaves every gradient in the flat buffer only; .grad may still name the tensors of
+                    # an earlier launch-by-launch step
+                    for p, v in zip(self.flat.params, self.flat.views):
+                        p.grad = v
+                    self._grads_bound = True
                 self.opt.step(self.bucketer.reduce_flat())
                 return loss
+        self._grads_bound = False
         self.bucketer.reset()
         loss = self._forward_backward(data, label)
         scale = self.bucketer.finish()

@@ -139,6 +139,24 @@ def test_other_tools():
     assert tools.mean_subtractor(z, 0) is None
 
 
+def test_temporal_slice_by_hand():
+    """tools.py:11-15 of the reference (which divides with `/` and cannot run under Python 3: parity unpinned by
+    reference fixtures): out[c, g, v, s * M + m] = data[c, g * step + s, v, m]."""
+    C, T, V, M, step = 2, 6, 3, 2, 3
+    d = np.arange(C * T * V * M, dtype=np.float64).reshape(C, T, V, M)
+    out = tools.temporal_slice(d, step)
+    assert out.shape == (C, T // step, V, step * M)
+    for c in range(C):
+        for g in range(T // step):
+            for v in range(V):
+                for s in range(step):
+                    for m in range(M):
+                        assert out[c, g, v, s * M + m] == d[c, g * step + s, v, m]
+    assert np.array_equal(tools.temporal_slice(d, 1), d)
+    with pytest.raises(ValueError):
+        tools.temporal_slice(d, 4)
+
+
 def test_feeder_contract(tmp_path):
     N = 6
     data = np.random.RandomState(0).randn(N, 3, 20, 5, 2).astype(np.float32)

@@ -807,3 +807,52 @@ def test_folded_inference_path(net, golden, ci, dtype):
     sd2["st_gcn_networks.4.residual.1.running_mean"] += 0.05
     lo, _, _ = O.model_forward(sd2, x, False)
     assert rel(cpu64(after), lo) < tol and rel(cpu64(after), cpu64(logits)) > 1e-4
+
+
+def test_folded_plan_follows_graph_replayed_training(net):
+    """Train (steps replayed from a HIP graph: no Python op touches a parameter or a running statistic, so no tensor
+    version advances), evaluate under no_grad, train on, evaluate again: the second evaluation must see the current
+    parameters and running statistics, i.e. agree with the general (unfolded) path on them and with the oracle, and
+    differ from the first.  Also: after a replay every p.grad is the parameter's slice of the flat gradient."""
+    mod, _ = net
+    m, tr = _fresh_trainer(mod, torch.float32, 0.0, True, lr=0.05)
+    xs = [O.det_input(2, 3, 24, 25, 2, tag=3400 + i).float().to(DEV) for i in range(4)]
+    l = torch.tensor([4, 9], device=DEV)
+    xe = O.det_input(2, 3, 24, 25, 2, tag=3450)
+    xed = xe.float().to(DEV)
+
+    def evaluate():
+        m.eval()
+        with torch.no_grad():
+            assert m._foldable()
+            folded = m(xed).clone()
+        general = m(xed).detach().clone()                       # grad enabled: separate BatchNorm stages
+        sd64 = {k: (v.detach().cpu().double() if v.is_floating_point() else v.detach().cpu()) for k, v in m.state_dict().items()}
+        lo, _, _ = O.model_forward(sd64, xe, False)
+        m.train()
+        return folded, general, lo
+
+    for i in range(4):
+        tr.step(xs[i % 4], l)
+    assert tr.graph_ready()
+    for p, v in zip(tr.flat.params, tr.flat.views):
+        assert p.grad is not None and p.grad.data_ptr() == v.data_ptr()
+    f1, g1, o1 = evaluate()
+    assert rel(cpu64(f1), o1) < 1e-4 and rel(cpu64(f1), cpu64(g1)) < 1e-4
+    # more replayed steps WITHOUT leaving eval/train through Model.train(): the trainer's own invalidation must do
+    m.eval()
+    with torch.no_grad():
+        m(xed)                                                  # a plan exists
+    for b in m.modules():
+        b.training = True                                       # back to train mode behind Model.train()'s back
+    for i in range(4):
+        tr.step(xs[i % 4], l)
+    for b in m.modules():
+        b.training = False
+    with torch.no_grad():
+        assert m._foldable()
+        f2 = m(xed).clone()
+    sd64 = {k: (v.detach().cpu().double() if v.is_floating_point() else v.detach().cpu()) for k, v in m.state_dict().items()}
+    o2, _, _ = O.model_forward(sd64, xe, False)
+    assert rel(cpu64(f2), o2) < 1e-4, rel(cpu64(f2), o2)
+    assert rel(cpu64(f2), cpu64(f1)) > 1e-3                     # the parameters did move

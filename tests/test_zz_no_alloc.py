@@ -39,6 +39,18 @@ def _both(x, dy, W, b, K):
     L.call("stgcn_gcn_agrad", L.dtype_code(xd.dtype), L.ptr(xd), L.ptr(wp), L.ptr(bd), L.ptr(dyd), L.ptr(dA1),
            B * T, V, Cin, Cout, K, L.ptr(ws), ws.numel(), L.stream_ptr())
     torch.cuda.synchronize()
+    # torch's statistics see only torch's own allocator; a hipMalloc inside the library would show in the device's
+    # free memory instead.  Measured around a repeated call (the first one on a device caches the array's address and
+    # may load the code object), with torch's own allocator quiet in between.
+    dA2 = torch.full((K, V, V), float("nan"), device=DEV)
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    L.call("stgcn_gcn_agrad_noalloc", L.dtype_code(xd.dtype), L.ptr(xd), L.ptr(wp), L.ptr(bd), L.ptr(dyd), L.ptr(dA2),
+           B * T, V, Cin, Cout, K, L.stream_ptr())
+    torch.cuda.synchronize()
+    free1 = torch.cuda.mem_get_info()[0]
+    assert free1 == free0, (free0, free1)
+    assert torch.equal(dA2, dA0)
     return dA0.cpu(), dA1.cpu(), grown
 
 

@@ -100,7 +100,8 @@ def cpu_baseline(n_clips, steps, threads):
     t = sum(times) / len(times)
     return {"value": round(n_clips / t, 3), "unit": "clips/s", "cores": threads, "kind": "port",
             "sample": "%d timed steps (1 warm-up) of the stock-PyTorch-operator restatement at N=%d clips, T=300, V=25, M=2, float32, "
-                      "dropout 0.5, SGD-nesterov" % (steps, n_clips)}
+                      "dropout 0.5, SGD-nesterov; a bounded sample: the per-clip rate is taken to be independent of the "
+                      "batch size (the GPU figure is at 64 clips)" % (steps, n_clips)}
 
 
 def cpu_baseline_oracle(n_clips, steps, threads):
@@ -133,6 +134,67 @@ def cpu_baseline_oracle(n_clips, steps, threads):
                       "SGD-nesterov" % (steps, n_clips)}
 
 
+def kinetics_train_record(dev, weights_init, steps=10, warmup=3):
+    """The reference's Kinetics training step (config/st_gcn/kinetics-skeleton/train.yaml:6-8, 17-33: openpose layout,
+    400 classes, no dropout, a 150-frame window, 256 clips over 8 GPUs = 32 per GPU) in both precisions, outside the
+    headline's timed region."""
+    from net.st_gcn import Model
+    from stgcn_rt.ddp import Trainer
+    gen = torch.Generator().manual_seed(7)
+    x = torch.randn(32, 3, 150, 18, 2, generator=gen).to(dev)
+    labels = torch.randint(0, 400, (32,), generator=gen).to(dev)
+    rec = {"workload": "Kinetics-skeleton training step, 32 clips per GPU, T=150, V=18, M=2, 400 classes, spatial K=3, no dropout, "
+                       "SGD-nesterov; HIP-graph replay", "steps": steps, "warmup": warmup}
+    for name, dtype in (("bf16", torch.bfloat16), ("fp32", torch.float32)):
+        torch.manual_seed(1234)
+        model = Model(3, 400, dict(layout="openpose", strategy="spatial"), True, compute_dtype=dtype).to(dev)
+        model.apply(weights_init)
+        model.train()
+        tr = Trainer(model, lr=0.1, momentum=0.9, weight_decay=1e-4, nesterov=True, graph=True)
+        for _ in range(warmup):
+            tr.step(x, labels)
+        tr.prepare_graph(x, labels)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = tr.step(x, labels)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        rec[name] = {"ms_per_step": round(dt * 1e3, 3), "clips_per_s": round(32 / dt, 1), "hip_graph": tr.graph_ready(),
+                     "final_loss": round(float(loss.item()), 4)}
+        del tr, model
+        torch.cuda.empty_cache()
+    return rec
+
+
+def infer_sweep_record(dev, weights_init, n_clips=1024, reps=3):
+    """Large-batch bf16 inference: eval-mode forward of N = 1024 clips (T = 300, M = 2) for both skeleton layouts and
+    the three partition strategies (K = 3 / 1 / 2: graph.py:85-119 of the reference), clips/s each."""
+    from net.st_gcn import Model
+    rec = {"workload": "eval-mode forward, bf16, N=%d clips, T=300, M=2, BatchNorm folded" % n_clips, "unit": "clips/s"}
+    for lay, ncls, V in (("ntu-rgb+d", 60, 25), ("openpose", 400, 18)):
+        x = torch.randn(n_clips, 3, 300, V, 2, device=dev, generator=torch.Generator(device=dev).manual_seed(3))
+        for strat in ("spatial", "uniform", "distance"):
+            torch.manual_seed(1234)
+            m = Model(3, ncls, dict(layout=lay, strategy=strat), True, compute_dtype=torch.bfloat16).to(dev)
+            m.apply(weights_init)
+            m.eval()
+            with torch.no_grad():
+                out = m(x)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    out = m(x)
+                torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / reps
+            assert bool(torch.isfinite(out).all())
+            rec["V%d_K%d_%s" % (V, m.A.shape[0], strat)] = round(n_clips / dt, 1)
+            del m, out
+        del x
+        torch.cuda.empty_cache()
+    return rec
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -147,6 +209,8 @@ def main():
     ap.add_argument("--cpu-clips", type=int, default=8)
     ap.add_argument("--single-dtype", action="store_true", help="time --dtype only (default: the other precision is timed too and reported as a nested record)")
     ap.add_argument("--no-graph", action="store_true", help="issue every step launch by launch instead of replaying the captured HIP graph")
+    ap.add_argument("--no-extra", action="store_true",
+                    help="skip the nested records of the other configurations (Kinetics training step, large-batch inference sweep)")
     ap.add_argument("--kernel-table", action="store_true", help="print the per-kernel time table to stderr")
     args = ap.parse_args()
 
@@ -301,6 +365,14 @@ def main():
         }
         if other is not None:
             line[other_name] = other
+        # the reference computes in float32 (processor/recognition.py:87-91): that record's figures at top level too
+        ref = head if args.dtype == "fp32" else other
+        line["reference_dtype"] = "fp32"
+        line["value_reference_dtype"] = None if ref is None else ref["value"]
+        line["ms_per_step_reference_dtype"] = None if ref is None else ref["ms_per_step"]
+        if world == 1 and not args.no_extra and args.batch == 64 and args.frames == 300:
+            line["kinetics_train"] = kinetics_train_record(dev, weights_init)
+            line["infer_n1024"] = infer_sweep_record(dev, weights_init)
         print(json.dumps(line))
     if dist.is_initialized():
         dist.destroy_process_group()

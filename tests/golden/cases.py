@@ -66,7 +66,12 @@ MODEL_CASES = [
     ("kin_distance_eval", "openpose", 400, 2, 38, 2, False),
     ("ntu_uniform_train", "ntu-rgb+d", 60, 2, 24, 2, True),
     ("kin_distance_train", "openpose", 400, 2, 38, 2, True),
+    # Every ReLU decision of this case has a margin: no pre-activation of any block lies within 1.8e-5 rms of zero in
+    # the float64 evaluation (input tag found by search, margin stored in the fixture), so a float32 evaluation takes
+    # the same decisions and its gradients must match the reference's directly.
+    ("ntu_margin_train", "ntu-rgb+d", 60, 2, 6, 1, True),
 ]
+INPUT_TAGS = {"ntu_margin_train": 5124}            # cases whose input tag is not 900 + index
 
 
 def strategy_of(name):
@@ -194,6 +199,6 @@ def block_inputs(case, tag0):
 def model_inputs(ci):
     name, lay, ncls, N, T, M, training = MODEL_CASES[ci]
     V = O.graph_edges(lay)[0]
-    x = O.det_input(N, 3, T, V, M, tag=900 + ci)
+    x = O.det_input(N, 3, T, V, M, tag=INPUT_TAGS.get(name, 900 + ci))
     labels = torch.tensor([(7 * i + 3) % ncls for i in range(N)])
     return x, labels

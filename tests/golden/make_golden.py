@@ -157,6 +157,10 @@ def gen_model():
         assert e < 1e-9, (name, "logits", e)
         assert abs(mloss.item() - loss.item()) < 1e-10
         if training:
+            margin = min((pre.abs().min() / pre.pow(2).mean().sqrt()).item() for bc in cache["blocks"] for pre in (bc["h1"], bc["s"]))
+            out[name + "/relu_margin"] = np.array(margin)  # smallest |pre-activation| / rms over every ReLU input
+            if "margin" in name:
+                assert margin > 1.5e-5, (name, margin)
             loss.backward()
             mg = O.model_backward(sd, cache, dlog, True)
             for k, prm in m.named_parameters():
@@ -230,6 +234,56 @@ def gen_sgd():
     print("sgd: 3 steps ok, losses", [float(out["loss%d" % i]) for i in range(3)])
 
 
+def gen_bf16_reference():
+    """What bfloat16 costs the REFERENCE: its own Model (float32 parameters) run under
+    torch.autocast("cpu", dtype=torch.bfloat16) on the training cases -- convolutions and the einsum in bfloat16, their
+    outputs stored in bfloat16 -- and its parameter gradients compared, tensor by tensor, with the float64 evaluation
+    that takes the SAME ReLU decisions (read from the run with forward hooks) and the same d loss / d logits.  Stored:
+    the relative L2 deviation of every gradient tensor, and of the logits from the float64 reference logits.  The GPU
+    tests bound the kernels' bfloat16 gradients by these numbers, measured the same way."""
+    out = {}
+    for ci, (name, lay, ncls, N, T, M, training) in enumerate(MODEL_CASES):
+        if not training:
+            continue
+        strat = strategy_of(name)
+        g = O.build_graph(lay, strat)
+        sd = O.det_state(3, ncls, g["A"], True, dtype=torch.float32)
+        x, labels = model_inputs(ci)
+        m = RefModel(3, ncls, dict(layout=lay, strategy=strat), True).float()
+        m.load_state_dict(sd, strict=True)
+        m.train()
+        masks = {}
+
+        def catch(i, slot):
+            def hook(mod, inp, res):
+                masks.setdefault(i, [None, None])[slot] = (res.detach() > 0).clone()
+            return hook
+        for i, blk in enumerate(m.st_gcn_networks):
+            blk.tcn[1].register_forward_hook(catch(i, 0))
+            blk.relu.register_forward_hook(catch(i, 1))
+        with torch.autocast("cpu", dtype=torch.bfloat16):
+            logits = m(x.float())
+            loss = torch.nn.functional.cross_entropy(logits, labels)
+        loss.backward()
+        assert logits.dtype == torch.bfloat16
+        sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+        plain, _, _ = O.model_forward(sd64, x, True)
+        _, cache, _ = O.model_forward(sd64, x, True, masks={i: tuple(v) for i, v in masks.items()})
+        _, dlog = O.cross_entropy(logits.detach().double(), labels)
+        ref_g = O.model_backward(sd64, cache, dlog, True)
+        devs = []
+        for k, prm in m.named_parameters():
+            if k.endswith("tcn.2.bias") or k.endswith("residual.0.bias"):
+                continue                                   # zero up to rounding noise behind a train-mode BatchNorm
+            d = ((prm.grad.double() - ref_g[k]).norm() / (ref_g[k].norm() + 1e-30)).item()
+            out[name + "/dev:" + k] = np.array(d)
+            devs.append(d)
+        out[name + "/logits_dev"] = np.array(((logits.detach().double() - plain).abs().max() / plain.abs().max()).item())
+        devs.sort()
+        print("bf16 reference %-22s logits %.2e, gradients worst %.2e median %.2e" % (name, float(out[name + "/logits_dev"]), devs[-1], devs[len(devs) // 2]))
+    np.savez_compressed(os.path.join(HERE, "bf16_ref.npz"), **out)
+
+
 def gen_feeder():
     """feeder/tools.py of the reference on closed-form clips, with the module-level generators it draws from
     (random, numpy.random) seeded per case: the tests hand the same seeds to random.Random / numpy RandomState."""
@@ -254,7 +308,7 @@ if __name__ == "__main__":
     if len(sys.argv) > 1:                      # e.g. `make_golden.py feeder model`: regenerate only those files
         for what in sys.argv[1:]:
             {"graph": gen_graphs, "gcn": gen_gcn, "gcn_temporal": gen_gcn_temporal, "block": gen_block, "model": gen_model, "sgd": gen_sgd,
-             "feeder": gen_feeder}[what]()
+             "feeder": gen_feeder, "bf16": gen_bf16_reference}[what]()
         sys.exit(0)
     gen_feeder()
     gen_graphs()
@@ -263,6 +317,7 @@ if __name__ == "__main__":
     gen_block()
     gen_model()
     gen_sgd()
+    gen_bf16_reference()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")

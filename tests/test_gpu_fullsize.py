@@ -56,13 +56,25 @@ FULL_CONV = [
     (64, 128, 300, 1, 2, 0, False),
     (128, 256, 150, 1, 2, 0, False),
 ]
+# The Kinetics training shapes (config/st_gcn/kinetics-skeleton/train.yaml:6-8, 17-33 of the reference: 256 clips over
+# 8 GPUs -> 32 clips x 2 persons = 64 samples, a 150-frame window, V = 18): 150 -> 75 -> 38 frames, the last stride-2
+# step from an odd length.  Entries with a trailing (V, B) run at that joint count and batch.
+FULL_CONV += [
+    (64, 64, 150, 9, 1, 4, True, 18, 64),
+    (128, 128, 150, 9, 2, 4, True, 18, 64),
+    (128, 128, 75, 9, 1, 4, True, 18, 64),
+    (256, 256, 75, 9, 2, 4, True, 18, 64),
+    (256, 256, 38, 9, 1, 4, True, 18, 64),
+    (64, 128, 150, 1, 2, 0, False, 18, 64),
+    (128, 256, 75, 1, 2, 0, False, 18, 64),
+]
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
 @pytest.mark.parametrize("case", FULL_CONV, ids=lambda c: "x".join(map(str, c)))
 def test_temporal_conv_full_size(rt, case, dtype):
-    Cin, Cout, T, kt, stride, pad, pro = case
-    V = 25
+    Cin, Cout, T, kt, stride, pad, pro = case[:7]
+    V, B = case[7:] if len(case) > 7 else (25, globals()["B"])
     tol = TOL[dtype]
     x = rnd((B, Cin, T, V), 1, dtype)
     W = rnd((Cout, Cin, kt), 2, dtype, 1.0 / np.sqrt(Cin * kt))
@@ -100,15 +112,22 @@ FULL_GCN = [
     (128, 128, 150),
     (128, 256, 150),
     (256, 256, 75),
+    # Kinetics training shapes: openpose layout (V = 18), 64 samples, 150 / 75 / 38 frames
+    (64, 64, 150, "openpose", 64),
+    (64, 128, 150, "openpose", 64),
+    (128, 128, 75, "openpose", 64),
+    (128, 256, 75, "openpose", 64),
+    (256, 256, 38, "openpose", 64),
 ]
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
 @pytest.mark.parametrize("case", FULL_GCN, ids=lambda c: "x".join(map(str, c)))
 def test_graph_conv_full_size(rt, case, dtype):
-    Cin, Cout, T = case
+    Cin, Cout, T = case[:3]
+    lay, B = case[3:] if len(case) > 3 else ("ntu-rgb+d", globals()["B"])
     tol = TOL[dtype]
-    A0 = torch.tensor(O.build_graph("ntu-rgb+d", "spatial")["A"], device=DEV)
+    A0 = torch.tensor(O.build_graph(lay, "spatial")["A"], device=DEV)
     K, V = A0.shape[0], A0.shape[1]
     A = A0 * (1.0 + rnd(A0.shape, 11, torch.float32, 0.2))       # A * edge importance
     x = rnd((B, Cin, T, V), 12, dtype)

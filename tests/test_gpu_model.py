@@ -263,6 +263,12 @@ def test_model(net, golden, ci, dtype):
         #    float64 ones.  tests/test_oracle_golden.py::test_one_relu_decision_moves_gradients shows the same
         #    sensitivity inside float64 alone.  bf16 is therefore bounded against the decision-consistent oracle below.
         assert direct < (1e-4 + 1.5e-2 * nflip if dtype == torch.float32 else 1.0), (direct, nflip)
+        if "margin" in name and dtype == torch.float32:
+            # every ReLU input of this case is at least 1.8e-5 rms away from zero in float64 (the fixture holds the
+            # margin), so float32 takes the reference's decisions and its gradients match the reference's own, with no
+            # decision handed over
+            assert float(G[name + "/relu_margin"]) > 1.5e-5
+            assert nflip == 0 and direct < tol, (nflip, direct)
 
         # 3. Against the oracle evaluated with the kernels' decisions and the GPU's d loss / d logits (the softmax turns
         #    an absolute logit error e into a relative probability error e, which says nothing about the backward kernels).
@@ -275,24 +281,35 @@ def test_model(net, golden, ci, dtype):
         if dtype == torch.float32:
             assert worst[1] < tol, worst
         else:
-            # bfloat16.  Activations, weights and the gradients between kernels are rounded to 8 significant bits at
-            # every kernel boundary, ~70 roundings deep by the last block; an exact evaluation of the reference's
-            # formulas with only those roundings (oracle.storage_rounding) deviates from float64 by 2-4 % on the
-            # tensors of the last blocks and on edge_importance.  That deviation is the format's, not the kernels':
-            # each tensor must stay within 2e-2, or within 1.6x of what the format itself costs that tensor (the two
-            # are different realisations of the same rounding noise), and the worst and the median over all tensors
-            # within 1.2x of the format's worst and median.
-            with O.storage_rounding(torch.bfloat16):
-                _, cache_q, _ = O.model_forward(sd64, x, True, masks=masks)
-                fmt_g = O.model_backward(sd64, cache_q, dlog, True)
-            fmt = {k: rel_l2(fmt_g[k], ref_g[k]) for k in got}
-            print("bf16-storage oracle vs float64 oracle: worst %.2e, median %.2e; kernels: worst %.2e, median %.2e"
-                  % (max(fmt.values()), sorted(fmt.values())[len(fmt) // 2], worst[1], sorted(errs.values())[len(errs) // 2]))
-            for k in got:
-                assert errs[k] < max(tol, 1.6 * fmt[k]), (k, errs[k], fmt[k])
+            # bfloat16.  The yardstick is the REFERENCE's own bfloat16 run: its Model under
+            # torch.autocast("cpu", dtype=torch.bfloat16) on this case, its gradients compared with the float64
+            # evaluation that takes ITS ReLU decisions and ITS d loss / d logits -- exactly the comparison made here for
+            # the kernels (tests/golden/make_golden.py::gen_bf16_reference -> bf16_ref.npz).  The reference's worst
+            # tensor deviates by 3.5-5.0e-2 and its median tensor by 1.8-2.1e-2 over the six training cases: activations,
+            # weights and the gradients between operators are rounded to 8 significant bits ~70 times by the last block.
+            # Bound: every tensor within 2e-2 or PER_TENSOR x the reference's deviation of that tensor (the two runs are
+            # different realisations of the same rounding noise), the worst and the median tensor within 1.2 x the
+            # reference's worst and median.
+            R = golden["bf16_ref"]
+            refdev = {k: float(R[name + "/dev:" + k]) for k in got}
             med = lambda d: sorted(d.values())[len(d) // 2]
-            assert worst[1] < min(6e-2, 1.2 * max(fmt.values())), (worst, max(fmt.values()))
-            assert med(errs) < max(tol, 1.2 * med(fmt)), (med(errs), med(fmt))
+            ratio = max(((errs[k] / refdev[k], k) for k in got if errs[k] > tol), default=(0.0, ""))
+            print("reference under bf16 autocast vs float64: worst %.2e, median %.2e; kernels: worst %.2e, median %.2e; "
+                  "largest kernel/reference ratio among tensors above 2e-2: %.2f (%s)"
+                  % (max(refdev.values()), med(refdev), worst[1], med(errs), ratio[0], ratio[1]))
+            PER_TENSOR = 1.6
+            for k in got:
+                assert errs[k] < max(tol, PER_TENSOR * refdev[k]), (k, errs[k], refdev[k])
+            assert worst[1] < 1.2 * max(refdev.values()), (worst, max(refdev.values()))
+            assert med(errs) < max(tol, 1.2 * med(refdev)), (med(errs), med(refdev))
+            if name in ("ntu_small_train", "kin_small_train_oddT"):
+                # diagnostic only: an exact evaluation of the reference's formulas that rounds to bfloat16 where the
+                # kernels store or feed an MFMA (oracle.storage_rounding) -- this build's own model of the format's cost
+                with O.storage_rounding(torch.bfloat16):
+                    _, cache_q, _ = O.model_forward(sd64, x, True, masks=masks)
+                    fmt_g = O.model_backward(sd64, cache_q, dlog, True)
+                fmt = {k: rel_l2(fmt_g[k], ref_g[k]) for k in got}
+                print("bf16-storage oracle vs float64 oracle (diagnostic): worst %.2e, median %.2e" % (max(fmt.values()), med(fmt)))
     if name.endswith("small_eval"):
         out, feat = m.extract_feature(x.float().to(DEV))
         assert rel(cpu64(out), G[name + "/feat_output"]) < tol

@@ -123,6 +123,7 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--lib", default=None, help="alternative build of libstgcn_hip.so (A/B timing on one device)")
+    ap.add_argument("--print-key", action="store_true", help="also print the launch's timing key (entry point + shape), as bench.py's tables name it")
     a = ap.parse_args()
     dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     if a.lib:
@@ -132,6 +133,13 @@ def main():
     first = True
     for case in a.cases:
         fn = make(case, dtype)
+        if a.print_key:
+            R.TIMING, R.TIMING_NAMES = {}, None
+            fn()
+            torch.cuda.synchronize()
+            for k in R.TIMING:
+                print("KEY %s %s" % (case, "|".join(map(str, k))), flush=True)
+            R.TIMING = None
         # the first launches of a process run at a lower clock: keep the device busy for a while before timing
         t_end = time.time() + (0.5 if first else 0.05)
         first = False

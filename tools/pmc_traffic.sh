@@ -1,0 +1,17 @@
+# HBM-side traffic of single kernels at the training step's shapes, from the memory-side counters: one rocprofv3 run per
+# (kernel case, counter), FETCH_SIZE and WRITE_SIZE in separate passes.  Run on the GPU box as `bash tools/pmc_traffic.sh`;
+# the summary (gpurun_out/prof/traffic.json) is merged into bench_traffic.json by hand.
+set -o pipefail
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof/traffic; rm -rf $O; mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+i=0
+for spec in "bf16 conv_t_epi:256:256" "bf16 gcn_fused:64:64" "bf16 gcn_fused_add:64:64" "bf16 bnbwd:64:64" "bf16 bofwd:64:64" \
+            "bf16 bob0:64:64" "bf16 bob1:64:64" "bf16 conv_wgrad:256:256" "fp32 conv_wgrad:256:256" "fp32 conv_t_epi:256:256"; do
+  set -- $spec
+  for ctr in FETCH_SIZE WRITE_SIZE; do
+    timeout -s KILL 150 rocprofv3 --pmc $ctr --output-format csv -d $O/c${i}_$ctr -- python3 $R/tools/kbench.py $2 --dtype $1 --iters 3 --print-key > $O/c${i}_$ctr.log 2>&1 || { echo "FAILED $spec $ctr"; tail -5 $O/c${i}_$ctr.log; exit 1; }
+    echo "done $spec $ctr"
+  done
+  i=$((i+1))
+done
+python3 $R/tools/pmc_traffic.py $O > $R/gpurun_out/prof/traffic.json && rm -rf $O/*/ && echo TRAFFIC_DONE

@@ -282,6 +282,12 @@ int conv_big_try(int dtype, const void* in, const void* w, void* out, const floa
                  double* stats, int B, int Tin, int Tout, int V, int Cin, int Cout, int ntaps, int stride, int pad, int dil,
                  int transposed, hipStream_t stream);
 
+// whole-width tiles for 128 / 256 output channels at an input stride of one frame, bf16 (conv_wide.hip); -1 = shape not covered
+int conv_wide_try(const void* in, const void* w, void* out, const float* bias, const float* pro_scale, const float* pro_shift,
+                  int epilogue, const void* aux, const float* ep_scale, const float* ep_shift, const float* ep_mean, const float* ep_rstd,
+                  double* stats, int B, int Tin, int Tout, int V, int Cin, int Cout, int ntaps, int stride, int pad, int dil,
+                  int transposed, hipStream_t stream);
+
 // streaming path for the strided 1-tap convolution in bf16 (conv1s.hip); -1 = shape not covered
 int conv1s_try(const void* in, const void* w, void* out, const float* bias, double* stats,
                int B, int Tin, int Tout, int V, int Cin, int Cout, int stride, int transposed, hipStream_t stream);
@@ -313,6 +319,11 @@ extern "C" int stgcn_conv_rows(int dtype, const void* in, const void* w_packed, 
     }
     if ((dtype == STGCN_BF16 || dtype == STGCN_F32) && B > 0 && Tin > 0 && Tout > 0 &&
         (epilogue == EPI_PLAIN || epilogue == EPI_ADD_RELU || (epilogue == EPI_RELU_BWD && aux && ep_scale && ep_shift && ep_mean && ep_rstd))) {
+        if (dtype == STGCN_BF16) {
+            const int rc = conv_wide_try(in, w_packed, out, bias, pro_scale, pro_shift, epilogue, aux, ep_scale, ep_shift, ep_mean, ep_rstd,
+                                         stats, B, Tin, Tout, V, Cin, Cout, ntaps, stride, pad, dil, transposed, (hipStream_t)stream);
+            if (rc >= 0) return rc;
+        }
         const int rc = conv_big_try(dtype, in, w_packed, out, bias, pro_scale, pro_shift, epilogue, aux, ep_scale, ep_shift, ep_mean, ep_rstd,
                                     stats, B, Tin, Tout, V, Cin, Cout, ntaps, stride, pad, dil, transposed, (hipStream_t)stream);
         if (rc >= 0) return rc;

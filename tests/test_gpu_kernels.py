@@ -80,6 +80,15 @@ CONV_CASES = [
     (2, 128, 128, 9, 25, 9, 2, 4, True),
     (1, 256, 256, 150, 25, 9, 2, 4, True),
     (2, 64, 128, 46, 18, 5, 2, 2, False),
+    # whole-width tiles (128 / 256 output channels, input stride 1): several tiles per sample and per workgroup, ragged
+    # last tile, both joint counts, input width different from the output width, fewer taps; their stride-2 relatives
+    # reach the same kernel through the per-parity launches of the transposed form
+    (3, 256, 256, 40, 18, 9, 1, 4, True),
+    (2, 128, 256, 75, 25, 9, 1, 4, False),
+    (5, 256, 128, 47, 25, 5, 1, 2, True),
+    (300, 64, 128, 9, 25, 9, 1, 4, True),
+    (2, 256, 256, 61, 25, 9, 2, 4, False),
+    (2, 128, 128, 150, 18, 7, 2, 3, True),
 ]
 
 
@@ -163,9 +172,11 @@ def test_conv_rows_transposed_and_wgrad(rt, case, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
-def test_conv_rows_relu_bwd_epilogue(rt, dtype):
+@pytest.mark.parametrize("shape", [(2, 64, 21, 25), (3, 128, 45, 25), (2, 256, 33, 18), (260, 256, 5, 25)], ids=lambda c: "x".join(map(str, c)))
+def test_conv_rows_relu_bwd_epilogue(rt, shape, dtype):
     from stgcn_rt import lib as L
-    B, Cc, T, V, kt = 2, 64, 21, 25, 9
+    B, Cc, T, V = shape
+    kt = 9
     y = q(t64((B, Cc, T, V), 31), dtype)
     do = q(t64((B, Cc, T, V), 32), dtype)
     W = q(t64((Cc, Cc, kt), 33) * 0.05, dtype)

@@ -21,12 +21,13 @@
 //   - The product is formed transposed, D'[channel][row] = W frag x X frag: a lane's four accumulator registers are
 //     four consecutive CHANNELS of one row, which leave through a wave-private LDS patch as 8-byte writes (a quarter of
 //     the 2-byte writes the untransposed layout needs) and go to memory as 16-byte pieces of whole 256-byte rows.
-//   - Weight tiles (BN x 32 channels of one tap = 16 or 8 KiB) cycle through four LDS buffers: tile g+3 is requested in
-//     step g, waited for with a counted vmcnt at the end of step g+1, published by the barrier of step g+2; its first
-//     four fragments are read during the second half of step g+2, the other four during the first half of step g+3,
-//     each into the registers whose MFMAs have just been issued.  One barrier per step (32 MFMAs per wave).
+//   - Weight tiles (BN x 32 channels of one tap = 16 or 8 KiB) cycle through four LDS buffers: tile g+3 is loaded into
+//     registers in step g-1, written to LDS in step g, published by the barriers of steps g+1 and g+2; its first four
+//     fragments are read during the second half of step g+2, the other four during the first half of step g+3, each
+//     into the registers whose MFMAs have just been issued.  One barrier per step (32 MFMAs per wave).
 #include "stgcn_common.h"
 #include <stdlib.h>
+#include <stdio.h>
 
 struct ConvWideArgs {
     const void* in; const void* w; void* out;
@@ -39,6 +40,7 @@ struct ConvWideArgs {
     int foff0, dfoff, wk0, dwk;
     int foff_min, foff_max;
     int tiles_per_sample;
+    long long* dbg;      // CWD_STAMP builds only: per-wave cycle sums of workgroup 0
 };
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
@@ -46,6 +48,37 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 __device__ __forceinline__ f32x4 mma16(const i32x4& a, const i32x4& b, const f32x4& c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
 }
+
+// Workgroup barrier over LDS traffic, as lds_barrier(), that also tells the compiler's wait-count bookkeeping that no LDS
+// read is outstanding (it does not look inside inline asm: without the builtin it closes every later wait for a
+// fragment with lgkmcnt(0), i.e. also waits for the reads issued just before).
+__device__ __forceinline__ void lds_barrier_known() {
+    __builtin_amdgcn_s_waitcnt(0xC07F);                 // lgkmcnt(0), every other counter left alone
+    asm volatile("s_barrier" ::: "memory");
+}
+
+// One LDS-DMA load: every lane's 16 bytes at gsrc go to LDS at lds_dst + 16 * lane (lds_dst wave-uniform).  Issued from
+// inline asm on purpose: the compiler models the builtin form (a FLAT instruction with a global and an LDS memory
+// operand) as "may complete out of order with everything" and from then on closes each of its own waits -- for a
+// fragment read, for a register load -- with a zero count, i.e. waits for whatever was issued last.  What it cannot see
+// it does not wait for; the kernel counts these loads itself (vmcnt before the barrier that publishes them).
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+#ifdef CWD_STAMP
+// stamps sit next to barriers only: s_memtime returns through the scalar cache, and a pending scalar load turns every
+// later LDS wait into a wait for everything
+#define CWD_T(x) long long x; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(x) :: "memory")
+#define CWD_TB(x) CWD_T(x)      /* never leave the scalar load in flight: its late write lands in whatever the register holds by then */
+#define CWD_ACC(i, v) dbgv[i] += (v)
+#else
+#define CWD_T(x)
+#define CWD_TB(x)
+#define CWD_ACC(i, v)
+#endif
 
 constexpr int CWD_ROW = 64;            // bytes of an LDS row: one 32-channel chunk
 constexpr int CWD_STG = 272;           // staging row: 128 channels + 16 bytes
@@ -67,9 +100,10 @@ __global__ __launch_bounds__(512) void conv_wide_kernel(ConvWideArgs a) {
     constexpr int STAT0 = ZOFF + CWD_ROW;                // [8 waves][2][128] floats
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, q = lane >> 4;
     const int wr = wave % WR, wc = wave / WR;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
     const int V = a.V, Cin = a.Cin, Cout = a.Cout, Tin = a.Tin, ntaps = a.ntaps;
     const int co0 = blockIdx.y * BN;
     const int Rv = a.Tv * V, Rreal = a.Tout_real * V;
@@ -77,6 +111,10 @@ __global__ __launch_bounds__(512) void conv_wide_kernel(ConvWideArgs a) {
     const int ntile_total = a.B * a.tiles_per_sample;
     float* stat = (float*)(smem + STAT0) + wave * 256;
 
+#ifdef CWD_STAMP
+    long long dbgv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    CWD_T(t_kernel0);
+#endif
     if (tid < CWD_ROW / 16) *(i32x4*)(smem + ZOFF + tid * 16) = zero16();
     for (int i = lane; i < 256; i += 64) stat[i] = 0.f;
 
@@ -89,18 +127,26 @@ __global__ __launch_bounds__(512) void conv_wide_kernel(ConvWideArgs a) {
         const int row = (wave * WTP + i) * 16 + (lane >> 2);
         wsrc[i] = (min(co0 + row, Cout - 1) * Cin + (((lane & 3) ^ swz_l) << 3)) * 2;
     }
-    auto dma_w = [&](int chunk, int tapi, int buf) {
-        const char* src = (const char*)a.w + ((size_t)(a.wk0 + tapi * a.dwk) * Cout * Cin + (size_t)chunk * 32) * 2;
-#pragma unroll
-        for (int i = 0; i < WTP; ++i)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + wsrc[i]),
-                                             (__attribute__((address_space(3))) void*)(smem + WT0 + buf * WT_BYTES + (wave * WTP + i) * 1024),
-                                             16, 0, 0);
-    };
+    // Weight tiles travel through registers: an LDS-DMA instruction costs the issuing wave 60-180 cycles (measured: this
+    // kernel without its weight DMA, two instructions per wave and step, ran 16 % shorter), a global_load_dwordx4 and a
+    // ds_write_b128 a fraction of that.  wreg holds the wave's share of ONE tile: loaded in step g-1, written to LDS in
+    // step g (same lane-linear 1-KiB pieces as a DMA would write), then reloaded.
+    i32x4 wreg[WTP], wreg1[WTP];                         // the tile loaded two steps ago / one step ago
     int wi_chunk = 0, wi_tap = 0;                        // the next weight tile to request (the sequence wraps per tile)
-    auto dma_w_next = [&](int buf) {
-        dma_w(wi_chunk, wi_tap, buf);
+    auto load_tile = [&](i32x4 (&dst)[WTP]) {
+        const char* src = (const char*)a.w + ((size_t)(a.wk0 + wi_tap * a.dwk) * Cout * Cin + (size_t)wi_chunk * 32) * 2;
+#pragma unroll
+        for (int i = 0; i < WTP; ++i) dst[i] = *(const i32x4*)(src + wsrc[i]);
         if (++wi_tap == ntaps) { wi_tap = 0; if (++wi_chunk == nchunks) wi_chunk = 0; }
+    };
+    auto load_w_next = [&]() {
+#pragma unroll
+        for (int i = 0; i < WTP; ++i) wreg[i] = wreg1[i];
+        load_tile(wreg1);
+    };
+    auto store_w = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < WTP; ++i) *(i32x4*)(smem + WT0 + buf * WT_BYTES + (wave * WTP + i) * 1024 + lane * 16) = wreg[i];
     };
     // window, LDS-DMA form: wave w brings pieces w, w + 8, ... (clamped: the count per wave is fixed, see the waits)
     auto dma_win = [&](int b, int flo, int wrows, int chunk, int buf) {
@@ -110,9 +156,7 @@ __global__ __launch_bounds__(512) void conv_wide_kernel(ConvWideArgs a) {
         for (int j = 0; j < WPW; ++j) {
             const int piece = min(wave + 8 * j, NWP - 1);
             const int row = min(piece * 16 + (lane >> 2), last);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + (size_t)row * Cin * 2),
-                                             (__attribute__((address_space(3))) void*)(smem + buf * WIN_BYTES + piece * 1024),
-                                             16, 0, 0);
+            glds16(base + (size_t)row * Cin * 2, lds0 + buf * WIN_BYTES + piece * 1024);
         }
     };
     // window, register form (prologue): thread -> logical slot (tid & 3) of rows (tid >> 2) + 128 i
@@ -168,13 +212,16 @@ __global__ __launch_bounds__(512) void conv_wide_kernel(ConvWideArgs a) {
     int wcur = 0;                                        // buffer of the current step's weight tile
     if constexpr (PRO) { fetch_win(b, flo, wrows, 0); commit_win(0, 0); }
     else dma_win(b, flo, wrows, 0, 0);
-    dma_w_next(0); dma_w_next(1); dma_w_next(2);
+    for (int t = 0; t < 3; ++t) { load_tile(wreg); store_w(t); }
+    load_tile(wreg);                                     // tile 3: written in step 0
+    load_tile(wreg1);                                    // tile 4: written in step 1
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     // B fragment of column subtile n: row wc * 128 + 16 n + l15 of the weight tile, slot q
     const int boff = (wc * 128 + l15) * CWD_ROW + ((q ^ (((l15 >> 2) & 1) << 1)) << 4);
 
     for (; ti < t_hi; ti += t_step) {
+        CWD_T(t_tile0);
         // this lane's rows (one per 16-row subtile) as window rows for frame offset 0
         int wbase[4];
         int tfr[4];                                      // frame of the row, or a value that fails every range check
@@ -204,11 +251,14 @@ __global__ __launch_bounds__(512) void conv_wide_kernel(ConvWideArgs a) {
 
         auto a_offsets = [&](int tapi, int (&aoff)[4]) {
             const int fo = a.foff0 + tapi * a.dfoff;
+            const int foV = fo * V;
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
-                const int fr = tfr[m] + fo;
-                const int row = wbase[m] + fo * V;
-                aoff[m] = (fr >= 0 && fr < Tin) ? row * CWD_ROW + ((q ^ (((row >> 2) & 1) << 1)) << 4) : ZOFF;
+                const int row = wbase[m] + foV;
+                const int off = (row << 6) | ((q ^ ((row >> 1) & 2)) << 4);
+                // one unsigned compare covers both ends of the sample (and the rows past the tile, whose frame is far
+                // below zero): a select, not a branch
+                aoff[m] = (unsigned)(tfr[m] + fo) < (unsigned)Tin ? off : ZOFF;
             }
         };
         // Fragments.  X (rows): am[] is this step's, nam[] the next step's, read during this step's second half.
@@ -224,10 +274,17 @@ __global__ __launch_bounds__(512) void conv_wide_kernel(ConvWideArgs a) {
 #pragma unroll
         for (int n = 0; n < 4; ++n) bq[n] = *(const i32x4*)(smem + WT0 + wcur * WT_BYTES + boff + n * 1024);
 
+        CWD_T(t_steps0);
+        CWD_ACC(0, t_steps0 - t_tile0);
         for (int chunk = 0; chunk < nchunks; ++chunk, ++cc) {
             const bool more = chunk + 1 < nchunks || tn < t_hi;        // a window follows this one
             for (int tapi = 0; tapi < ntaps; ++tapi) {
-                lds_barrier();
+                CWD_TB(t_b0);
+#ifndef CWD_AB_NO_BARRIER
+                lds_barrier_known();
+#endif
+                CWD_T(t_b1);
+                CWD_ACC(1, t_b1 - t_b0);
                 const bool newwin = tapi + 1 == ntaps;
                 const int wnext = (wcur + 1) & (CWD_NWT - 1);
                 const char* bc = smem + WT0 + wcur * WT_BYTES + boff;
@@ -240,34 +297,57 @@ __global__ __launch_bounds__(512) void conv_wide_kernel(ConvWideArgs a) {
                     for (int m = 0; m < 4; ++m) acc[m][n] = mma16(bq[n], am[m], acc[m][n]);
                     // (the last step of a tile reads ahead like every other: what it fetches is dropped, the next tile's
                     // first step reads its own fragments; every address stays inside the buffers)
+#ifndef CWD_AB_NO_READS
                     if (n < 4) bq[n + 4] = *(const i32x4*)(bc + (n + 4) * 1024);
                     else {
                         bq[n - 4] = *(const i32x4*)(bn + (n - 4) * 1024);
                         nam[n - 4] = *(const i32x4*)(wn + aoff[n - 4]);
                     }
+#else
+                    if (n >= 4) nam[n - 4] = am[n - 4];
+#endif
+#ifndef CWD_AB_NO_DMA
                     if (n == 1) {
-                        // requests of this step: the next window at the first tap, one weight tile always (tile g+3 into
-                        // the buffer of tile g-1, whose last reads were in the first half of step g-1)
+                        // tile g+3 (in registers since the step before) goes to the buffer of tile g-1, whose last reads
+                        // were in the first half of step g-1; then the requests of this step: the next window at the
+                        // first tap, the next weight tile always
+#ifndef CWD_AB_NO_WSTORE
+                        store_w((wcur + 3) & (CWD_NWT - 1));
+#endif
+#ifndef CWD_AB_NO_WIN
                         if (tapi == 0 && more) {
                             const bool same = chunk + 1 < nchunks;
                             if constexpr (PRO) fetch_win(same ? b : nb, same ? flo : nflo, same ? wrows : nwrows, same ? chunk + 1 : 0);
                             else dma_win(same ? b : nb, same ? flo : nflo, same ? wrows : nwrows, same ? chunk + 1 : 0, (cc + 1) & 1);
                         }
-                        dma_w_next((wcur + 3) & (CWD_NWT - 1));
+#endif
+#ifndef CWD_AB_NO_WLOAD
+                        load_w_next();
+#endif
                     }
+#endif
                     if constexpr (PRO) { if (n == 3 && tapi == 2 && more) commit_win(chunk + 1 < nchunks ? chunk + 1 : 0, (cc + 1) & 1); }
-                    if (n == 2) a_offsets(newwin ? 0 : tapi + 1, aoff);
+#ifndef CWD_AB_NO_AOFF
+                    if (n == 2) {
+                        // pure arithmetic floats to the top of the step unless something pins it behind the first MFMAs
+                        int tnext = newwin ? 0 : tapi + 1;
+                        asm volatile("" : "+v"(tnext));
+                        a_offsets(tnext, aoff);
+                    }
+#endif
                     __builtin_amdgcn_sched_barrier(0);
                 }
 #pragma unroll
                 for (int m = 0; m < 4; ++m) am[m] = nam[m];
                 wcur = wnext;
-                // everything requested before this step has landed: weight tile g+2, whose first half is read during the
-                // second half of step g+1, and -- from the second tap on -- the next window
-                if (tapi == 0 && more) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(WTP + (PRO ? NRP : WPW)) : "memory");
-                else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(WTP) : "memory");
+                // (no wait here: the store of the weight registers in the next step waits for their load, the youngest
+                // request of this step, and with it for the window pieces requested before it)
+                CWD_TB(t_w1);
+                CWD_ACC(3, t_w1 - t_b1);
+                CWD_ACC(6, 1);
             }
         }
+        CWD_T(t_e0);
         lds_barrier();                                   // every wave is done with the last window
 
         // ---- epilogue: wave-private patch (16 rows x 128 channels) in the window buffer just consumed ------------
@@ -359,9 +439,17 @@ __global__ __launch_bounds__(512) void conv_wide_kernel(ConvWideArgs a) {
             }
         }
         b = nb; r0 = nr0; r1 = nr1; flo = nflo; wrows = nwrows;
+        CWD_T(t_e1);
+        CWD_ACC(4, t_e1 - t_e0);
     }
+#ifdef CWD_STAMP
+    CWD_T(t_kernel1);
+    dbgv[5] = t_kernel1 - t_kernel0;
+    if (a.dbg && blockIdx.x == 0 && lane == 0)
+        for (int i = 0; i < 8; ++i) a.dbg[wave * 8 + i] = dbgv[i];
+#endif
 
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // weight tiles requested for steps that never came
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the weight tile requested for a step that never came
     if (EPI != 2 && a.stats) {
         __syncthreads();
         if (tid < 2 * BN) {
@@ -392,7 +480,23 @@ static int launch_conv_wide(ConvWideArgs& a, hipStream_t stream) {
     auto kern = conv_wide_kernel<WR, WC, EPI, PRO>;
     static std::atomic<uint64_t> lds_ok{0};
     if (stgcn_allow_big_lds((const void*)kern, lds_ok) != STGCN_OK) return STGCN_ERR_LAUNCH;
+#ifdef CWD_STAMP
+    static long long* dbg = nullptr;
+    if (!dbg) { hipMalloc(&dbg, 64 * sizeof(long long)); }
+    hipMemsetAsync(dbg, 0, 64 * sizeof(long long), stream);
+    a.dbg = dbg;
+#endif
     hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)(a.Cout / BN)), dim3(512), lds, stream, a);
+#ifdef CWD_STAMP
+    if (getenv("STGCN_CW_DBG")) {
+        long long h[64];
+        hipStreamSynchronize(stream);
+        hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost);
+        for (int w = 0; w < 8; ++w)
+            fprintf(stderr, "wave %d: kernel %lld  tile-start %lld  barrier %lld  (unused %lld)  step-after-barrier %lld  epilogue %lld  steps %lld\n",
+                    w, h[w * 8 + 5], h[w * 8 + 0], h[w * 8 + 1], h[w * 8 + 2], h[w * 8 + 3], h[w * 8 + 4], h[w * 8 + 6]);
+    }
+#endif
     return hipGetLastError() == hipSuccess ? STGCN_OK : STGCN_ERR_LAUNCH;
 }
 
@@ -434,6 +538,7 @@ int conv_wide_try(const void* in, const void* w, void* out, const float* bias, c
     a.aux = aux; a.ep_scale = ep_scale; a.ep_shift = ep_shift; a.ep_mean = ep_mean; a.ep_rstd = ep_rstd; a.stats = stats;
     a.B = B; a.Tin = Tin; a.V = V; a.Cin = Cin; a.Cout = Cout; a.Tout_real = Tout;
     a.tiles_per_sample = 0;
+    a.dbg = nullptr;
     if (stride == 1) {
         if (ntaps < 4 || ntaps > 9) return -1;
         a.os = 1; a.opar = 0; a.Tv = Tout; a.ntaps = ntaps;

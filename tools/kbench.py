@@ -123,6 +123,8 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--lib", default=None, help="alternative build of libstgcn_hip.so (A/B timing on one device)")
+    ap.add_argument("--rotate", type=int, default=1, help="cycle through this many independent sets of tensors (a training step never "
+                    "re-reads what the caches, the memory-side cache included, still hold from the launch before)")
     ap.add_argument("--print-key", action="store_true", help="also print the launch's timing key (entry point + shape), as bench.py's tables name it")
     a = ap.parse_args()
     dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
@@ -132,7 +134,14 @@ def main():
     import time
     first = True
     for case in a.cases:
-        fn = make(case, dtype)
+        fns = [make(case, dtype) for _ in range(max(1, a.rotate))]
+        fn = fns[0]
+        if len(fns) > 1:
+            state = {"i": 0}
+
+            def fn(fns=fns, state=state):
+                state["i"] = (state["i"] + 1) % len(fns)
+                return fns[state["i"]]()
         if a.print_key:
             R.TIMING, R.TIMING_NAMES = {}, None
             fn()

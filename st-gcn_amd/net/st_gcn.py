@@ -56,6 +56,12 @@ class Model(nn.Module):
         self.fcn = nn.Conv2d(256, num_class, kernel_size=1)
         self._packer = None
         self._plan = None                               # (key, folded inference parameters): see _eval_plan
+        # A trainer that backpropagates in two segments (stgcn_rt.ddp.Trainer with more than one rank and a HIP graph)
+        # sets split_block = i: a training forward then keeps the activation entering block i and the per-block
+        # A * importance tensors, the roots of the second segment.
+        self.split_block = None
+        self._mid = None
+        self._a_eff = None
 
     def _pack_specs(self, dtype):
         specs = []
@@ -199,7 +205,17 @@ class Model(nn.Module):
             a_eff = EdgeImportanceFn.apply(self.A, *self.edge_importance)       # A * importance, all blocks at once
         else:
             a_eff = [self.A * importance for importance in self.edge_importance]
+        self._mid, self._a_eff = None, None
         for i, gcn in enumerate(self.st_gcn_networks):
+            if self.split_block == i and torch.is_grad_enabled():
+                # The late blocks take A * importance through a view each: a node of its own per block, at which a
+                # backward segment can stop.  (Stopping at the outputs of the ONE node that forms all the products makes
+                # the autograd engine treat every block that feeds that node as needed, i.e. run the whole backward.)
+                a_eff = list(a_eff)
+                for j in range(i, len(a_eff)):
+                    if isinstance(a_eff[j], torch.Tensor) and a_eff[j].requires_grad:
+                        a_eff[j] = a_eff[j].view(a_eff[j].shape)
+                self._mid, self._a_eff = h, a_eff
             # global average pool over (T, V) fused into the last block (st_gcn.py:85 of the reference)
             want_pool = pool_last and i == last
             h, pooled = gcn._run(h, a_eff[i], want_pool, packs=packs[i], counters=counters, drop_step=step)

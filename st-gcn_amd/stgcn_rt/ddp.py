@@ -241,19 +241,26 @@ class Trainer:
     shape and replayed from then on: the host issues one graph launch instead of ~200 kernel launches through
     autograd, which is what bounds small per-GPU batches.  Inputs are copied into the graph's static buffers; the
     dropout masks advance through a step count kept on the device; collectives and the optimizer launch stay
-    outside the graph (the learning rate may change freely, and no RCCL call is ever captured), so with more than one
-    rank the buckets are all-reduced after the replay instead of under the backward.  If the capture fails the
-    trainer says so on stderr and keeps stepping launch by launch."""
+    outside the graph (the learning rate may change freely, and no RCCL call is ever captured).  With more than one
+    rank the step is captured as two graphs (SPLIT_BLOCK): the gradients of the first backward segment are all-reduced
+    while the second is replayed.  If the capture fails the trainer says so on stderr and keeps stepping launch by
+    launch."""
 
     GRAPH_WARMUP = 2
+    # With more than one rank the captured step is TWO graphs: forward, loss and the backward of the head and of blocks
+    # SPLIT_BLOCK.. (three quarters of the parameters) in the first, the rest of the backward in the second.  The
+    # all-reduce of the first segment's gradients is issued between the two replays and runs under the second; no
+    # collective is ever captured.
+    SPLIT_BLOCK = 7
 
-    def __init__(self, model, lr=0.1, momentum=0.9, weight_decay=1e-4, nesterov=True, bucket_bytes=4 << 20, graph=False):
+    def __init__(self, model, lr=0.1, momentum=0.9, weight_decay=1e-4, nesterov=True, bucket_bytes=4 << 20, graph=False, split=None):
         self.model = model
         self.flat = FlatParams(model, reverse_execution_order(model))
         self.bucketer = GradBucketer(self.flat, bucket_bytes)
         self.opt = SGD(self.flat, lr, momentum, weight_decay, nesterov)
         self.loss_fn = torch.nn.CrossEntropyLoss()
         self.use_graph = bool(graph)
+        self.split = split                    # capture the step as two graphs: None = when there is more than one rank
         self._graphs = {}                     # (data shape, label shape) -> (graph, static data, static label, static loss)
         self._eager_steps = 0
         self._grads_bound = False             # whether every p.grad is the parameter's slice of the flat gradient
@@ -274,10 +281,88 @@ class Trainer:
         loss.backward()
         return loss.detach()                  # not the graph's root: a kept loss would keep every autograd node of the step alive
 
+    def _split_point(self):
+        """Index into the flat buffers where the parameters of the second backward segment begin, or None when the
+        model cannot be split (not an ST-GCN Model, or an order in which the late parameters are no prefix)."""
+        m = self.model
+        blocks = getattr(m, "st_gcn_networks", None)
+        if blocks is None or not hasattr(m, "split_block") or len(blocks) <= self.SPLIT_BLOCK:
+            return None
+        late = {id(p) for p in m.fcn.parameters()}
+        for i in range(self.SPLIT_BLOCK, len(blocks)):
+            late |= {id(p) for p in blocks[i].parameters()}
+        n = 0
+        while n < len(self.flat.params) and id(self.flat.params[n]) in late:
+            n += 1
+        if n == 0 or n != len([p for p in self.flat.params if id(p) in late]):
+            return None
+        return n
+
+    def _capture_split(self, data, label, nlate):
+        """Two graphs sharing one memory pool (always replayed in capture order): see SPLIT_BLOCK.  Gradients are taken
+        with torch.autograd.grad and copied into the flat buffer inside the graphs; the roots of the second segment
+        are the activation entering block SPLIT_BLOCK and the late blocks' A * importance tensors, whose gradients the
+        first segment returns (the importance product is ONE autograd node for all blocks: it runs in the second)."""
+        from . import ops as P
+        if P.TIMING is not None:
+            return None
+        m, flat = self.model, self.flat
+        sx, sl = data.clone(), label.clone()
+        g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        late, early = flat.params[:nlate], flat.params[nlate:]
+        self.bucketer.hooks_enabled = False
+        m.split_block = self.SPLIT_BLOCK
+        try:
+            torch.cuda.synchronize()
+            with torch.cuda.graph(g1, capture_error_mode="thread_local"):
+                flat.zero_grad()
+                loss = self.loss_fn(m(sx), sl)
+                mid = m._mid
+                adj = [t for t in (m._a_eff[self.SPLIT_BLOCK:] if m._a_eff is not None else []) if isinstance(t, torch.Tensor) and t.requires_grad]
+                roots = [mid] + adj
+                gr = torch.autograd.grad(loss, roots + late, allow_unused=True)
+                groots, glate = gr[:len(roots)], gr[len(roots):]
+                dst = [flat.views[i] for i, g in enumerate(glate) if g is not None]
+                torch._foreach_copy_(dst, [g for g in glate if g is not None])
+                for i, g in enumerate(glate):
+                    if g is None:
+                        flat.views[i].zero_()
+                loss = loss.detach()
+            with torch.cuda.graph(g2, pool=g1.pool(), capture_error_mode="thread_local"):
+                keep = [(r, g) for r, g in zip(roots, groots) if g is not None]
+                ge = torch.autograd.grad([r for r, _ in keep], early, grad_outputs=[g for _, g in keep], allow_unused=True)
+                dst = [flat.views[nlate + i] for i, g in enumerate(ge) if g is not None]
+                torch._foreach_copy_(dst, [g for g in ge if g is not None])
+                for i, g in enumerate(ge):
+                    if g is None:
+                        flat.views[nlate + i].zero_()
+            del gr, groots, glate, ge, keep, roots, mid, adj
+        except Exception as e:                # stay in this process: step launch by launch from now on
+            import sys
+            print("stgcn Trainer: HIP graph capture (two segments) failed (%s: %s); stepping without a graph" % (type(e).__name__, e), file=sys.stderr)
+            if os.environ.get("STGCN_GRAPH_DEBUG"):
+                import traceback
+                traceback.print_exc()
+            self.use_graph = False
+            self.bucketer.hooks_enabled = True
+            m.split_block = None
+            m._mid = m._a_eff = None
+            torch.cuda.synchronize()
+            return None
+        self.bucketer.hooks_enabled = True
+        m.split_block = None
+        m._mid = m._a_eff = None
+        return ((g1, g2, flat.offsets[nlate]), sx, sl, loss)
+
     def _capture(self, data, label):
         from . import ops as P
         if P.TIMING is not None:
             return None
+        want = self.bucketer.distributed and os.environ.get("STGCN_GRAPH_SPLIT", "1") != "0" if self.split is None else self.split
+        if want:
+            nlate = self._split_point()
+            if nlate is not None:
+                return self._capture_split(data, label, nlate)
         sx, sl = data.clone(), label.clone()
         g = torch.cuda.CUDAGraph()
         self.bucketer.hooks_enabled = False
@@ -327,14 +412,28 @@ class Trainer:
                     sx.copy_(data, non_blocking=True)
                 if label.data_ptr() != sl.data_ptr():
                     sl.copy_(label, non_blocking=True)
-                g.replay()
+                if isinstance(g, tuple):
+                    # two segments: the late parameters' gradients travel while the second segment runs
+                    g1, g2, cut = g
+                    dist_on = self.bucketer.distributed
+                    g1.replay()
+                    hs = [all_reduce_sum(self.flat.grad[:cut], self.bucketer.group)] if dist_on else []
+                    g2.replay()
+                    if dist_on:
+                        hs.append(all_reduce_sum(self.flat.grad[cut:], self.bucketer.group))
+                    for h in hs:
+                        h.wait()
+                    scale = 1.0 / self.bucketer.world
+                else:
+                    g.replay()
+                    scale = None
                 if not self._grads_bound:
                     # the replay leaves every gradient in the flat buffer only; .grad may still name the tensors of
                     # an earlier launch-by-launch step
                     for p, v in zip(self.flat.params, self.flat.views):
                         p.grad = v
                     self._grads_bound = True
-                self.opt.step(self.bucketer.reduce_flat())
+                self.opt.step(self.bucketer.reduce_flat() if scale is None else scale)
                 return loss
         self._grads_bound = False
         self.bucketer.reset()

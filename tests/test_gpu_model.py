@@ -440,14 +440,14 @@ def test_training_learns_a_separable_task(net, dtype):
     assert res["topk"][1] >= 0.9, res["topk"]
 
 
-def _fresh_trainer(mod, dtype, dropout, graph, lr=0.01, wd=1e-4):
+def _fresh_trainer(mod, dtype, dropout, graph, lr=0.01, wd=1e-4, split=None):
     from stgcn_rt.ddp import Trainer
     g = O.build_graph("ntu-rgb+d", "spatial")
     sd = O.det_state(3, 60, g["A"], True, dtype=torch.float32)
     m = mod.Model(3, 60, dict(layout="ntu-rgb+d", strategy="spatial"), True, dropout=dropout, compute_dtype=dtype).to(DEV)
     m.load_state_dict(sd, strict=True)
     m.train()
-    return m, Trainer(m, lr=lr, momentum=0.9, weight_decay=wd, nesterov=True, graph=graph)
+    return m, Trainer(m, lr=lr, momentum=0.9, weight_decay=wd, nesterov=True, graph=graph, split=split)
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
@@ -873,3 +873,32 @@ def test_folded_plan_follows_graph_replayed_training(net):
     o2, _, _ = O.model_forward(sd64, xe, False)
     assert rel(cpu64(f2), o2) < 1e-4, rel(cpu64(f2), o2)
     assert rel(cpu64(f2), cpu64(f1)) > 1e-3                     # the parameters did move
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+def test_two_segment_graph_equals_one_graph(net, dtype):
+    """With more than one rank the trainer captures a step as TWO graphs (forward + the backward of the head and the last
+    blocks; the rest of the backward) and all-reduces the first segment's gradients while the second is replayed.  The
+    split itself, forced here without a process group: six steps with dropout end in the same parameters, bit for bit,
+    as the one-graph trainer and as the launch-by-launch trainer."""
+    mod, _ = net
+    x = O.det_input(4, 3, 48, 25, 2, tag=3270).float().to(DEV)
+    l = torch.tensor([4, 9, 33, 58], device=DEV)
+    runs = []
+    for graph, split in ((False, None), (True, False), (True, True)):
+        torch.manual_seed(99)
+        m, tr = _fresh_trainer(mod, dtype, 0.5, graph, lr=0.01, split=split)
+        losses = [float(tr.step(x, l).detach()) for _ in range(6)]
+        torch.cuda.synchronize()
+        assert tr.graph_ready() == graph
+        if split:
+            ent = next(iter(tr._graphs.values()))
+            assert isinstance(ent[0], tuple) and 0 < ent[0][2] < tr.flat.flat.numel()        # two graphs, a cut inside the buffer
+            assert ent[0][2] > tr.flat.flat.numel() // 2                                   # most parameters travel early
+            for p, v in zip(tr.flat.params, tr.flat.views):
+                assert p.grad is not None and p.grad.data_ptr() == v.data_ptr()
+        runs.append((losses, tr.flat.flat.detach().clone(), tr.flat.grad.detach().clone()))
+        del m, tr
+    for losses, params, grads in runs[1:]:
+        assert losses == runs[0][0], (losses, runs[0][0])
+        assert torch.equal(params, runs[0][1]) and torch.equal(grads, runs[0][2])

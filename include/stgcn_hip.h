@@ -5,13 +5,14 @@
  * stock PyTorch operators.  Each entry point below replaces the operator call(s) cited with it.
  *
  * Conventions
- *   - plain pointers and sizes only; every pointer is DEVICE memory owned by the caller;
+ *   - plain pointers and sizes only; every pointer is DEVICE memory owned by the caller (the two host-side
+ *     arguments of the deferred-sum calls, `sum_list` and `workspace_used`, are named as such where they appear);
  *   - activations are channels-last: physical [B][T][V][C], C contiguous (a torch tensor of
  *     logical shape [B,C,T,V] in torch.channels_last memory format); dtype STGCN_F32 or
  *     STGCN_BF16; per-channel parameters and all gradients of parameters are float32;
  *   - `stream` is a hipStream_t; calls only enqueue work: no allocation, no synchronisation;
  *   - return value: 0 ok, 1 invalid argument, 2 launch failed, 3 workspace too small, 4 problem exceeds the
- *     library's static scratch array (stgcn_gcn_agrad_noalloc only);
+ *     library's static scratch array (stgcn_gcn_agrad_noalloc only), 5 sum list full (the _deferred calls only);
  *   - `stats` buffers are double[2*C]; kernels ADD into them, the caller zeroes them first;
  *   - channel counts of MFMA operands must be multiples of one 32-byte k-step (16 bf16 / 8 f32);
  *     conv_rows / conv_wgrad input channels multiples of one 128-byte chunk (64 bf16 / 32 f32).
@@ -95,6 +96,36 @@ int stgcn_gcn_agrad_noalloc(int dtype, const void* x, const void* w_packed, cons
 int stgcn_gcn_wgrad(int dtype, const void* x, const void* dy, const float* adj, float* dW, float* db,
                     int NF, int V, int Cin, int Cout, int K,
                     void* workspace, size_t workspace_bytes, void* stream);
+
+/* Deferred sums.  The three parameter-gradient entry points above run two stages: kernels that write per-workgroup
+ * partial sums into the workspace, and one small launch that adds the partials in a fixed order.  The _deferred forms
+ * run the first stage only and append the second to a SUM LIST; stgcn_sum_list_run then adds the partials of every
+ * entry on the list in ONE launch (a block's temporal-convolution, graph-convolution and adjacency gradients: one
+ * launch instead of three or four).  Results are bit-identical to the undeferred calls given the same workspace_bytes.
+ *   sum_list        caller-owned HOST memory of STGCN_SUM_LIST_BYTES bytes, zero-filled before its first use; holds at
+ *                   most 8 sums (a call adds one or two).  A full list makes the call return status 5, nothing launched.
+ *   workspace       as above, but it must not overlap the part of any workspace that an entry still on the list uses:
+ *                   *workspace_used receives the bytes, from `workspace` on, that have to stay untouched until
+ *                   stgcn_sum_list_run has been ISSUED on the same stream (stream order does the rest).
+ * Replaces: the same autograd gradients as stgcn_conv_wgrad / stgcn_gcn_agrad / stgcn_gcn_wgrad. */
+#define STGCN_SUM_LIST_BYTES 1024
+int stgcn_conv_wgrad_deferred(int dtype, const void* in, const void* dout, float* dW,
+                              const float* pro_scale, const float* pro_shift,
+                              int B, int Tin, int Tout, int V, int Cin, int Cout,
+                              int ntaps, int stride, int pad, int dil,
+                              void* workspace, size_t workspace_bytes, void* sum_list, size_t* workspace_used, void* stream);
+int stgcn_gcn_agrad_deferred(int dtype, const void* x, const void* w_packed, const float* bias, const void* dy,
+                             float* dA, int NF, int V, int Cin, int Cout, int K,
+                             void* workspace, size_t workspace_bytes, void* sum_list, size_t* workspace_used, void* stream);
+int stgcn_gcn_wgrad_deferred(int dtype, const void* x, const void* dy, const float* adj, float* dW, float* db,
+                             int NF, int V, int Cin, int Cout, int K,
+                             void* workspace, size_t workspace_bytes, void* sum_list, size_t* workspace_used, void* stream);
+/* Appends dst[i] = (float)src[i], i < n, to the list: finished double-precision sums (the bias gradients that
+ * stgcn_block_out_bwd accumulates) become float32 gradients in the list's launch instead of one of their own.  Host
+ * work only; `src` must hold its final values by the time stgcn_sum_list_run is issued.  Status 5 when the list is full. */
+int stgcn_sum_list_add_cast(void* sum_list, const double* src, float* dst, size_t n);
+/* Launches the sums waiting on the list (none: no launch) and empties it. */
+int stgcn_sum_list_run(void* sum_list, void* stream);
 
 /* BatchNorm bookkeeping: batch statistics -> mean / rstd / scale=gamma*rstd / shift=beta-mean*scale, running
  * statistics update (momentum, unbiased variance); eval mode reads the running statistics instead.

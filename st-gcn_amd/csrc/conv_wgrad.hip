@@ -218,19 +218,14 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(ConvWgradArgs a) {
     }
 }
 
-// dW[co][ci][tap] = sum_part slab[part][tap][co][ci]   (torch conv weight layout [Cout][Cin][ntaps][1])
-__global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float* slab, float* dW, int nparts, int ntaps, int Cout, int Cin) {
-    __shared__ float red[256];
-    const size_t n = (size_t)ntaps * Cout * Cin;
-    const size_t i = (size_t)blockIdx.x * 64 + (threadIdx.x & 63);
-    const float s = slab_sum64(slab, nparts, n, i, red);
-    if (threadIdx.x < 64 && i < n) {
-        const int ci = (int)(i % Cin);
-        const size_t rest = i / Cin;
-        const int co = (int)(rest % Cout);
-        const int tap = (int)(rest / Cout);
-        dW[((size_t)co * Cin + ci) * ntaps + tap] = s;
-    }
+// The partials' fixed-order sum, dW[co][ci][tap] = sum_part slab[part][tap][co][ci] (torch conv weight layout
+// [Cout][Cin][ntaps][1]): launched at once, or left on the caller's list.
+static int conv_wgrad_sum(StgcnSumList* list, const float* slab, float* dW, int nparts, int ntaps, int Cout, int Cin, hipStream_t stream) {
+    StgcnPendingSum s{};
+    s.slab = slab; s.out1 = dW; s.out2 = nullptr;
+    s.n1 = (unsigned long long)ntaps * Cout * Cin; s.n2 = 0;
+    s.nparts = nparts; s.kind = STGCN_SUM_CONV_W; s.ntaps = ntaps; s.cout = Cout; s.cin = Cin;
+    return stgcn_sum_or_defer(list, s, stream);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -531,7 +526,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_ring_kernel(ConvWgradRingArgs 
 // -1: shape not covered
 static int conv_wgrad_ring_try(const void* in, const void* dout, float* dW, const float* pro_scale, const float* pro_shift,
                                int B, int Tin, int Tout, int V, int Cin, int Cout, int ntaps, int stride,
-                               void* ws, size_t ws_bytes, hipStream_t stream) {
+                               void* ws, size_t ws_bytes, StgcnSumList* list, hipStream_t stream) {
     if (Cin % 64 != 0 || Cout % 8 != 0 || V > 32 || V < 1 || (ntaps != 9 && ntaps != 1)) return -1;
     if (stride != 1 && stride != 2) return -1;
     ConvWgradRingArgs a;
@@ -568,13 +563,11 @@ static int conv_wgrad_ring_try(const void* in, const void* dout, float* dW, cons
         default: hipLaunchKernelGGL((conv_wgrad_ring_kernel<2, 9>), grid, dim3(512), lds, stream, a); break;
     }
     if (hipGetLastError() != hipSuccess) return STGCN_ERR_LAUNCH;
-    const size_t n = (size_t)ntaps * Cout * Cin;
-    hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3(slab_sum_grid(n)), dim3(256), 0, stream, a.slab, dW, nwg, ntaps, Cout, Cin);
-    return hipGetLastError() == hipSuccess ? STGCN_OK : STGCN_ERR_LAUNCH;
+    return conv_wgrad_sum(list, a.slab, dW, nwg, ntaps, Cout, Cin, stream);
 }
 
 template <typename T>
-static int conv_wgrad_run(ConvWgradArgs& a, float* dW, size_t ws_bytes, hipStream_t stream) {
+static int conv_wgrad_run(ConvWgradArgs& a, float* dW, size_t ws_bytes, StgcnSumList* list, hipStream_t stream) {
     constexpr int CT = 128 / ET<T>::ES;
     if (a.Cin % CT != 0 || a.Cout <= 0 || a.ntaps < 1 || a.ntaps > 9 || a.V <= 0 || a.V > 64) return STGCN_ERR_ARG;
     const int nf = (128 - 2) / a.V + 2;
@@ -611,21 +604,18 @@ static int conv_wgrad_run(ConvWgradArgs& a, float* dW, size_t ws_bytes, hipStrea
 #undef CW_LAUNCH
     rc = hipGetLastError() == hipSuccess ? STGCN_OK : STGCN_ERR_LAUNCH;
     if (rc) return rc;
-    const size_t n = (size_t)a.ntaps * a.Cout * a.Cin;
-    hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3(slab_sum_grid(n)), dim3(256), 0, stream,
-                       a.slab, dW, nseg * wave_parts, a.ntaps, a.Cout, a.Cin);
-    return hipGetLastError() == hipSuccess ? STGCN_OK : STGCN_ERR_LAUNCH;
+    return conv_wgrad_sum(list, a.slab, dW, nseg * wave_parts, a.ntaps, a.Cout, a.Cin, stream);
 }
 
 // streaming path for the 1-tap convolution of the residual branch (conv1s.hip); -1 = shape not covered
 int conv1s_wgrad_try(const void* in, const void* dout, int B, int Tin, int Tout, int V, int Cin, int Cout, int stride,
                      void* ws, size_t ws_bytes, int* nparts, hipStream_t stream);
 
-extern "C" int stgcn_conv_wgrad(int dtype, const void* in, const void* dout, float* dW,
-                                const float* pro_scale, const float* pro_shift,
-                                int B, int Tin, int Tout, int V, int Cin, int Cout,
-                                int ntaps, int stride, int pad, int dil,
-                                void* workspace, size_t workspace_bytes, void* stream) {
+static int conv_wgrad_any(int dtype, const void* in, const void* dout, float* dW,
+                          const float* pro_scale, const float* pro_shift,
+                          int B, int Tin, int Tout, int V, int Cin, int Cout,
+                          int ntaps, int stride, int pad, int dil,
+                          void* workspace, size_t workspace_bytes, StgcnSumList* list, hipStream_t stream) {
     if (!in || !dout || !dW || !workspace) return STGCN_ERR_ARG;
     if ((pro_scale == nullptr) != (pro_shift == nullptr)) return STGCN_ERR_ARG;
     ConvWgradArgs a;
@@ -635,21 +625,43 @@ extern "C" int stgcn_conv_wgrad(int dtype, const void* in, const void* dout, flo
     a.win_rows_max = 0; a.tiles_per_sample = 0; a.nseg = 0;
     if (dtype == STGCN_BF16 && ntaps == 1 && pad == 0 && dil == 1 && !pro_scale) {
         int nparts = 0;
-        const int rc = conv1s_wgrad_try(in, dout, B, Tin, Tout, V, Cin, Cout, stride, workspace, workspace_bytes, &nparts, (hipStream_t)stream);
-        if (rc == STGCN_OK) {
-            const size_t n = (size_t)Cout * Cin;
-            hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3(slab_sum_grid(n)), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, dW, nparts, 1, Cout, Cin);
-            return hipGetLastError() == hipSuccess ? STGCN_OK : STGCN_ERR_LAUNCH;
-        }
+        const int rc = conv1s_wgrad_try(in, dout, B, Tin, Tout, V, Cin, Cout, stride, workspace, workspace_bytes, &nparts, stream);
+        if (rc == STGCN_OK) return conv_wgrad_sum(list, (const float*)workspace, dW, nparts, 1, Cout, Cin, stream);
         if (rc > 0) return rc;
     }
     if (dtype == STGCN_BF16 && dil == 1 && pad == (ntaps - 1) / 2 && B > 0 && Tin > 0 &&
         Tout == (Tin - 1) / stride + 1) {
         const int rc = conv_wgrad_ring_try(in, dout, dW, pro_scale, pro_shift, B, Tin, Tout, V, Cin, Cout, ntaps, stride,
-                                           workspace, workspace_bytes, (hipStream_t)stream);
+                                           workspace, workspace_bytes, list, stream);
         if (rc >= 0) return rc;
     }
-    if (dtype == STGCN_BF16) return conv_wgrad_run<bf16>(a, dW, workspace_bytes, (hipStream_t)stream);
-    if (dtype == STGCN_F32) return conv_wgrad_run<float>(a, dW, workspace_bytes, (hipStream_t)stream);
+    if (dtype == STGCN_BF16) return conv_wgrad_run<bf16>(a, dW, workspace_bytes, list, stream);
+    if (dtype == STGCN_F32) return conv_wgrad_run<float>(a, dW, workspace_bytes, list, stream);
     return STGCN_ERR_ARG;
+}
+
+extern "C" int stgcn_conv_wgrad(int dtype, const void* in, const void* dout, float* dW,
+                                const float* pro_scale, const float* pro_shift,
+                                int B, int Tin, int Tout, int V, int Cin, int Cout,
+                                int ntaps, int stride, int pad, int dil,
+                                void* workspace, size_t workspace_bytes, void* stream) {
+    return conv_wgrad_any(dtype, in, dout, dW, pro_scale, pro_shift, B, Tin, Tout, V, Cin, Cout, ntaps, stride, pad, dil,
+                          workspace, workspace_bytes, nullptr, (hipStream_t)stream);
+}
+
+// The same partial sums with the final sum left on the caller's list (stgcn_sum_list_run launches it together with
+// the other sums waiting there); *workspace_used = bytes of the workspace that must stay untouched until then.
+extern "C" int stgcn_conv_wgrad_deferred(int dtype, const void* in, const void* dout, float* dW,
+                                         const float* pro_scale, const float* pro_shift,
+                                         int B, int Tin, int Tout, int V, int Cin, int Cout,
+                                         int ntaps, int stride, int pad, int dil,
+                                         void* workspace, size_t workspace_bytes, void* sum_list, size_t* workspace_used, void* stream) {
+    StgcnSumList* list = (StgcnSumList*)sum_list;
+    if (!list || !workspace_used) return STGCN_ERR_ARG;
+    const int first = list->n;
+    const int rc = conv_wgrad_any(dtype, in, dout, dW, pro_scale, pro_shift, B, Tin, Tout, V, Cin, Cout, ntaps, stride, pad, dil,
+                                  workspace, workspace_bytes, list, (hipStream_t)stream);
+    if (rc != STGCN_OK) { list->n = first; return rc; }
+    *workspace_used = stgcn_sum_list_extent(list, first, workspace);
+    return STGCN_OK;
 }

@@ -547,6 +547,16 @@ int conv_wide_try(const void* in, const void* w, void* out, const float* bias, c
     if (off) return -1;
     if ((Cout != 128 && Cout != 256) || Cin % 32 != 0 || Cin < 64 || V < 1 || V > 32 || dil != 1) return -1;
     if (epilogue == 1 && pro_scale) return -1;
+    // One workgroup per compute unit walks the tiles; with fewer tiles than compute units part of the chip would
+    // idle, and conv_big's tiles (a quarter or half the size) fill it better: an 8-clip step's 128 tiles run 1.5x
+    // faster there.  STGCN_CONV_WIDE_ANY_GRID (read on every call) lifts the condition: tests run this kernel on small
+    // shapes with it.
+    {
+        const int bm = Cout == 256 ? 256 : 512;
+        const int tv = stride == 1 ? Tout : (Tout + 1) / 2;
+        const long tiles = (long)B * ceil_div_i(tv * V, bm);
+        if (tiles < stgcn_num_cus() && getenv("STGCN_CONV_WIDE_ANY_GRID") == nullptr) return -1;
+    }
     ConvWideArgs a;
     a.in = in; a.w = w; a.out = out; a.bias = bias; a.pro_scale = pro_scale; a.pro_shift = pro_shift;
     a.aux = aux; a.ep_scale = ep_scale; a.ep_shift = ep_shift; a.ep_mean = ep_mean; a.ep_rstd = ep_rstd; a.stats = stats;

@@ -609,36 +609,14 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : 2) void gcn_agrad_kernel(G
     }
 }
 
-// sum of the partials [nparts][n1 + n2] into out1[n1] and out2[n2] (out2 may be null)
-__global__ __launch_bounds__(256) void sum_parts2_kernel(const float* slab, float* out1, size_t n1, float* out2, size_t n2, int nparts) {
-    __shared__ float red[256];
-    const size_t n = n1 + n2;
-    const size_t i = (size_t)blockIdx.x * 64 + (threadIdx.x & 63);
-    const float s = slab_sum64(slab, nparts, n, i, red);
-    if (threadIdx.x < 64 && i < n) {
-        if (i < n1) out1[i] = s;
-        else if (out2) out2[i - n1] = s;
-    }
-}
-
-__global__ __launch_bounds__(256) void sum_parts_kernel(const float* slab, float* out, int nparts, size_t n) {
-    __shared__ float red[256];
-    const size_t i = (size_t)blockIdx.x * 64 + (threadIdx.x & 63);
-    const float s = slab_sum64(slab, nparts, n, i, red);
-    if (threadIdx.x < 64 && i < n) out[i] = s;
-}
-
-// Few elements, many parts (dA: 3*V*V sums of up to 512 partials): one wave per element, lane l adds parts
-// l, l+64, ...; the lanes are then folded with a fixed butterfly, so the order of additions never changes.
-__global__ __launch_bounds__(256) void sum_parts_wave_kernel(const float* slab, float* out, int nparts, size_t n) {
-    const size_t i = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (i >= n) return;
-    float s = 0.f;
-    for (int p = lane; p < nparts; p += 64) s += slab[(size_t)p * n + i];
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d);
-    if (lane == 0) out[i] = s;
+// The fixed-order sum of partials [nparts][n1 + n2] into out1[n1] and out2[n2] (out2 may be null): launched at once,
+// or left on the caller's list.  `wave`: few elements and many parts (dA: 3*V*V sums of up to 512 partials), one wave
+// per element.
+static int gcn_sum(StgcnSumList* list, const float* slab, float* out1, size_t n1, float* out2, size_t n2, int nparts, bool wave, hipStream_t stream) {
+    StgcnPendingSum s{};
+    s.slab = slab; s.out1 = out1; s.out2 = out2; s.n1 = n1; s.n2 = n2; s.nparts = nparts;
+    s.kind = wave ? STGCN_SUM_WAVE : STGCN_SUM_PLAIN;
+    return stgcn_sum_or_defer(list, s, stream);
 }
 
 template <typename T, int NA, int NWV, bool RAG>
@@ -663,7 +641,7 @@ static int gcn_agrad_launch(GcnAgradArgs& a, dim3 grid, size_t lds, int nwv, hip
 }
 
 template <typename T>
-static int gcn_agrad_run(GcnAgradArgs& a, float* dA, size_t ws_bytes, hipStream_t stream) {
+static int gcn_agrad_run(GcnAgradArgs& a, float* dA, size_t ws_bytes, StgcnSumList* list, hipStream_t stream) {
     constexpr int ES = ET<T>::ES, KSTEP = ET<T>::KSTEP;
     if (a.Cin % KSTEP != 0 || a.Cin <= 0 || a.Cin > 32 * KSTEP || a.Cout % 8 != 0 || a.K < 1 || a.K > GCN_KMAX || a.V < 1 || a.V > 32 || a.NF < 1) return STGCN_ERR_ARG;
     const size_t rsw = (size_t)a.Cin * ES + 16;
@@ -700,20 +678,38 @@ static int gcn_agrad_run(GcnAgradArgs& a, float* dA, size_t ws_bytes, hipStream_
         default: rc = gcn_agrad_launch<T, 0>(a, grid, lds, nwv, stream); break;
     }
     if (rc != STGCN_OK) return rc;
-    hipLaunchKernelGGL(sum_parts_wave_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, a.slab, dA, gx * gy, n);
-    return hipGetLastError() == hipSuccess ? STGCN_OK : STGCN_ERR_LAUNCH;
+    return gcn_sum(list, a.slab, dA, n, nullptr, 0, gx * gy, true, stream);
+}
+
+static int gcn_agrad_any(int dtype, const void* x, const void* w_packed, const float* bias, const void* dy,
+                         float* dA, int NF, int V, int Cin, int Cout, int K,
+                         void* workspace, size_t workspace_bytes, StgcnSumList* list, hipStream_t stream) {
+    if (!x || !w_packed || !dy || !dA || !workspace) return STGCN_ERR_ARG;
+    GcnAgradArgs a;
+    a.x = x; a.w = w_packed; a.bias = bias; a.dy = dy; a.slab = (float*)workspace;
+    a.NF = NF; a.V = V; a.Cin = Cin; a.Cout = Cout; a.K = K; a.ntw = 1;
+    if (dtype == STGCN_BF16) return gcn_agrad_run<bf16>(a, dA, workspace_bytes, list, stream);
+    if (dtype == STGCN_F32) return gcn_agrad_run<float>(a, dA, workspace_bytes, list, stream);
+    return STGCN_ERR_ARG;
 }
 
 extern "C" int stgcn_gcn_agrad(int dtype, const void* x, const void* w_packed, const float* bias, const void* dy,
                                float* dA, int NF, int V, int Cin, int Cout, int K,
                                void* workspace, size_t workspace_bytes, void* stream) {
-    if (!x || !w_packed || !dy || !dA || !workspace) return STGCN_ERR_ARG;
-    GcnAgradArgs a;
-    a.x = x; a.w = w_packed; a.bias = bias; a.dy = dy; a.slab = (float*)workspace;
-    a.NF = NF; a.V = V; a.Cin = Cin; a.Cout = Cout; a.K = K; a.ntw = 1;
-    if (dtype == STGCN_BF16) return gcn_agrad_run<bf16>(a, dA, workspace_bytes, (hipStream_t)stream);
-    if (dtype == STGCN_F32) return gcn_agrad_run<float>(a, dA, workspace_bytes, (hipStream_t)stream);
-    return STGCN_ERR_ARG;
+    return gcn_agrad_any(dtype, x, w_packed, bias, dy, dA, NF, V, Cin, Cout, K, workspace, workspace_bytes, nullptr, (hipStream_t)stream);
+}
+
+// The same partial sums with the final sum left on the caller's list (see stgcn_conv_wgrad_deferred).
+extern "C" int stgcn_gcn_agrad_deferred(int dtype, const void* x, const void* w_packed, const float* bias, const void* dy,
+                                        float* dA, int NF, int V, int Cin, int Cout, int K,
+                                        void* workspace, size_t workspace_bytes, void* sum_list, size_t* workspace_used, void* stream) {
+    StgcnSumList* list = (StgcnSumList*)sum_list;
+    if (!list || !workspace_used) return STGCN_ERR_ARG;
+    const int first = list->n;
+    const int rc = gcn_agrad_any(dtype, x, w_packed, bias, dy, dA, NF, V, Cin, Cout, K, workspace, workspace_bytes, list, (hipStream_t)stream);
+    if (rc != STGCN_OK) { list->n = first; return rc; }
+    *workspace_used = stgcn_sum_list_extent(list, first, workspace);
+    return STGCN_OK;
 }
 
 // The same computation for callers that may not allocate (code under HIP graph capture, serving loops, harnesses
@@ -748,8 +744,8 @@ extern "C" int stgcn_gcn_agrad_noalloc(int dtype, const void* x, const void* w_p
     GcnAgradArgs a;
     a.x = x; a.w = w_packed; a.bias = bias; a.dy = dy; a.slab = (float*)scratch;
     a.NF = NF; a.V = V; a.Cin = Cin; a.Cout = Cout; a.K = K; a.ntw = 1;
-    if (dtype == STGCN_BF16) rc = gcn_agrad_run<bf16>(a, dA, GCN_SCRATCH_BYTES, (hipStream_t)stream);
-    else if (dtype == STGCN_F32) rc = gcn_agrad_run<float>(a, dA, GCN_SCRATCH_BYTES, (hipStream_t)stream);
+    if (dtype == STGCN_BF16) rc = gcn_agrad_run<bf16>(a, dA, GCN_SCRATCH_BYTES, nullptr, (hipStream_t)stream);
+    else if (dtype == STGCN_F32) rc = gcn_agrad_run<float>(a, dA, GCN_SCRATCH_BYTES, nullptr, (hipStream_t)stream);
     else return STGCN_ERR_ARG;
     return rc == STGCN_ERR_WORKSPACE ? STGCN_ERR_SCRATCH : rc;       // partials of this shape exceed the static array
 }
@@ -1133,7 +1129,7 @@ __global__ __launch_bounds__(768) void gcn_wgrad_wide_kernel(GcnWgradWideArgs a)
 
 // -1: shape outside the wide kernel's domain
 static int gcn_wgrad_wide_try(const void* x, const void* dy, const float* adj, float* dW, float* db,
-                              int NF, int V, int Cin, int Cout, int K, void* ws, size_t ws_bytes, hipStream_t stream) {
+                              int NF, int V, int Cin, int Cout, int K, void* ws, size_t ws_bytes, StgcnSumList* list, hipStream_t stream) {
     const int cit = ceil_div_i(Cin, 32);
     if (!(cit == 1 || cit == 2 || cit == 4 || cit == 8) || Cin % 8 != 0 || Cout % 8 != 0 || K < 1 || K > GCN_KMAX || V < 1 || V > 32) return -1;
     GcnWgradWideArgs a;
@@ -1172,13 +1168,11 @@ static int gcn_wgrad_wide_try(const void* x, const void* dy, const float* adj, f
     else hipLaunchKernelGGL(gcn_wgrad_wide_kernel<4>, grid, block, lds, stream, a);
     if (hipGetLastError() != hipSuccess) return STGCN_ERR_LAUNCH;
     // one reduction over the combined partials, written to the two outputs
-    const size_t n = nW + nB;
-    hipLaunchKernelGGL(sum_parts2_kernel, dim3(slab_sum_grid(n)), dim3(256), 0, stream, a.slabW, dW, nW, db, nB, gx);
-    return hipGetLastError() == hipSuccess ? STGCN_OK : STGCN_ERR_LAUNCH;
+    return gcn_sum(list, a.slabW, dW, nW, db, nB, gx, false, stream);
 }
 
 template <typename T>
-static int gcn_wgrad_run(GcnWgradArgs& a, float* dW, float* db, size_t ws_bytes, hipStream_t stream) {
+static int gcn_wgrad_run(GcnWgradArgs& a, float* dW, float* db, size_t ws_bytes, StgcnSumList* list, hipStream_t stream) {
     constexpr int ES = ET<T>::ES, KSTEP = ET<T>::KSTEP;
     if (a.Cin % KSTEP != 0 || a.Cin <= 0 || a.Cout % 8 != 0 || a.Cout <= 0 || a.K < 1 || a.K > GCN_KMAX || a.V < 1 || a.V > 32 || a.NF < 1) return STGCN_ERR_ARG;
     // input channels per workgroup: the widest group of whole k-steps, at most 64 channels, that divides Cin
@@ -1205,26 +1199,43 @@ static int gcn_wgrad_run(GcnWgradArgs& a, float* dW, float* db, size_t ws_bytes,
     if (stgcn_allow_big_lds((const void*)kern, lds_ok) != STGCN_OK) return STGCN_ERR_LAUNCH;
     hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)ncot, (unsigned)ncig), dim3(256), lds, stream, a);
     if (hipGetLastError() != hipSuccess) return STGCN_ERR_LAUNCH;
-    hipLaunchKernelGGL(sum_parts_kernel, dim3(slab_sum_grid(nW)), dim3(256), 0, stream, a.slabW, dW, gx, nW);
-    if (db) {
-        hipLaunchKernelGGL(sum_parts_kernel, dim3(slab_sum_grid(nB)), dim3(256), 0, stream, a.slabB, db, gx, nB);
+    int rc = gcn_sum(list, a.slabW, dW, nW, nullptr, 0, gx, false, stream);
+    if (rc == STGCN_OK && db) rc = gcn_sum(list, a.slabB, db, nB, nullptr, 0, gx, false, stream);
+    return rc;
+}
+
+static int gcn_wgrad_any(int dtype, const void* x, const void* dy, const float* adj, float* dW, float* db,
+                         int NF, int V, int Cin, int Cout, int K,
+                         void* workspace, size_t workspace_bytes, StgcnSumList* list, hipStream_t stream) {
+    if (!x || !dy || !adj || !dW || !workspace) return STGCN_ERR_ARG;
+    GcnWgradArgs a;
+    a.x = x; a.dy = dy; a.adj = adj; a.slabW = (float*)workspace; a.slabB = nullptr;
+    a.NF = NF; a.V = V; a.Cin = Cin; a.Cout = Cout; a.K = K; a.cig = 0; a.iters = 0;
+    if (dtype == STGCN_BF16 && NF > 0) {
+        const int rc = gcn_wgrad_wide_try(x, dy, adj, dW, db, NF, V, Cin, Cout, K, workspace, workspace_bytes, list, stream);
+        if (rc >= 0) return rc;
     }
-    return hipGetLastError() == hipSuccess ? STGCN_OK : STGCN_ERR_LAUNCH;
+    if (dtype == STGCN_BF16) return gcn_wgrad_run<bf16>(a, dW, db, workspace_bytes, list, stream);
+    if (dtype == STGCN_F32) return gcn_wgrad_run<float>(a, dW, db, workspace_bytes, list, stream);
+    return STGCN_ERR_ARG;
 }
 
 // dW is [K][Cout][Cin] f32 (the torch conv weight [K*Cout, Cin, 1, 1]); db is [K][Cout] or null.
 extern "C" int stgcn_gcn_wgrad(int dtype, const void* x, const void* dy, const float* adj, float* dW, float* db,
                                int NF, int V, int Cin, int Cout, int K,
                                void* workspace, size_t workspace_bytes, void* stream) {
-    if (!x || !dy || !adj || !dW || !workspace) return STGCN_ERR_ARG;
-    GcnWgradArgs a;
-    a.x = x; a.dy = dy; a.adj = adj; a.slabW = (float*)workspace; a.slabB = nullptr;
-    a.NF = NF; a.V = V; a.Cin = Cin; a.Cout = Cout; a.K = K; a.cig = 0; a.iters = 0;
-    if (dtype == STGCN_BF16 && NF > 0) {
-        const int rc = gcn_wgrad_wide_try(x, dy, adj, dW, db, NF, V, Cin, Cout, K, workspace, workspace_bytes, (hipStream_t)stream);
-        if (rc >= 0) return rc;
-    }
-    if (dtype == STGCN_BF16) return gcn_wgrad_run<bf16>(a, dW, db, workspace_bytes, (hipStream_t)stream);
-    if (dtype == STGCN_F32) return gcn_wgrad_run<float>(a, dW, db, workspace_bytes, (hipStream_t)stream);
-    return STGCN_ERR_ARG;
+    return gcn_wgrad_any(dtype, x, dy, adj, dW, db, NF, V, Cin, Cout, K, workspace, workspace_bytes, nullptr, (hipStream_t)stream);
+}
+
+// The same partial sums with the final sums left on the caller's list (see stgcn_conv_wgrad_deferred).
+extern "C" int stgcn_gcn_wgrad_deferred(int dtype, const void* x, const void* dy, const float* adj, float* dW, float* db,
+                                        int NF, int V, int Cin, int Cout, int K,
+                                        void* workspace, size_t workspace_bytes, void* sum_list, size_t* workspace_used, void* stream) {
+    StgcnSumList* list = (StgcnSumList*)sum_list;
+    if (!list || !workspace_used) return STGCN_ERR_ARG;
+    const int first = list->n;
+    const int rc = gcn_wgrad_any(dtype, x, dy, adj, dW, db, NF, V, Cin, Cout, K, workspace, workspace_bytes, list, (hipStream_t)stream);
+    if (rc != STGCN_OK) { list->n = first; return rc; }
+    *workspace_used = stgcn_sum_list_extent(list, first, workspace);
+    return STGCN_OK;
 }

@@ -16,6 +16,7 @@
 #define STGCN_ERR_LAUNCH 2
 #define STGCN_ERR_WORKSPACE 3
 #define STGCN_ERR_SCRATCH 4   // the problem needs more than the library's static scratch array holds
+#define STGCN_ERR_LIST_FULL 5 // a sum list has no room for another pending sum: run it first
 
 #define STGCN_F32 0
 #define STGCN_BF16 1
@@ -197,3 +198,37 @@ __device__ __forceinline__ float slab_sum64(const float* slab, int nparts, size_
     return tot;
 }
 static inline unsigned slab_sum_grid(size_t n) { return (unsigned)((n + 63) / 64); }
+
+// ---- pending sums ------------------------------------------------------------------------------------------------
+// The kernels that produce parameter gradients write per-workgroup partials [nparts][n1 + n2] (f32) and leave the
+// fixed-order sum over the parts to a second launch.  A launcher describes that sum with a StgcnPendingSum and hands
+// it to stgcn_sum_or_defer: with no list the sum is launched at once, with a list it is appended and the caller runs
+// the whole list (sums of several launchers, one launch) with stgcn_sum_list_launch.  Either way the same device code
+// adds the same parts in the same order.
+enum { STGCN_SUM_PLAIN = 0,      // out1[i] (i < n1) and out2[i - n1] (out2 may be null) = sum over parts
+       STGCN_SUM_WAVE = 1,       // few elements, many parts: one wave per element, lanes fold with a fixed butterfly
+       STGCN_SUM_CONV_W = 2,     // element i = (tap, co, ci) of [ntaps][cout][cin] goes to out1[(co*cin + ci)*ntaps + tap]
+       STGCN_SUM_CAST = 3 };     // no sum: `slab` holds n1 doubles (finished sums of double atomics), out1[i] = (float)slab[i]
+struct StgcnPendingSum {
+    const float* slab; float* out1; float* out2;
+    unsigned long long n1, n2;
+    int nparts, kind, ntaps, cout, cin, reserved;
+};
+constexpr int STGCN_MAX_PENDING = 8;
+struct StgcnSumList { int n; int reserved; StgcnPendingSum d[STGCN_MAX_PENDING]; };   // host memory, caller-owned
+static_assert(sizeof(StgcnSumList) <= 1024, "a sum list fits the size the public header promises");
+
+int stgcn_sum_or_defer(StgcnSumList* list, const StgcnPendingSum& s, hipStream_t stream);
+int stgcn_sum_list_launch(StgcnSumList* list, hipStream_t stream);
+// bytes of [base, ...) that the slabs of the list's entries from index `first` on reach into
+static inline size_t stgcn_sum_list_extent(const StgcnSumList* list, int first, const void* base) {
+    size_t e = 0;
+    if (!list) return 0;
+    for (int i = first; i < list->n; ++i) {
+        const StgcnPendingSum& d = list->d[i];
+        if (d.kind == STGCN_SUM_CAST) continue;           // reads the caller's own buffer, not the workspace
+        const size_t end = (size_t)((const char*)(d.slab + (size_t)d.nparts * (d.n1 + d.n2)) - (const char*)base);
+        if (end > e) e = end;
+    }
+    return e;
+}

@@ -5,6 +5,7 @@
   DataBnFn      Model.forward input normalisation    (net/st_gcn.py:72-78)
   HeadFn        pooling + fcn                        (net/st_gcn.py:85-90)
 """
+import contextlib
 import os
 
 import torch
@@ -260,46 +261,50 @@ class StGcnBlockFn(torch.autograd.Function):
         # identity residual: its gradient is the masked incoming gradient.  With a stored dout and the forward's bit
         # mask, the graph-conv dX kernel masks dout itself and nothing is written for it.
         mask_in_dx = kind == "identity" and dout is not None and dpool is None and ctx.relu_mask is not None
-        dO, dR, g, stats2, statsr, dbt, dbr_f, (dg2, db2, dgr, dbetar) = P.block_out_bwd(
-            dout, out, o, r_, bn2, f32(g2), bnr, f32(gr) if kind == "conv" else None, kind == "identity" and not mask_in_dx,
-            p, seed, training, dpool=dpool, relu_mask=ctx.relu_mask, want_bn_grads=True)
-
-        # temporal conv: weight grad (input = relu(bn1(y)) recomputed in the prologue), then data grad fused with
-        # the ReLU mask and the BN1-backward sums
         side = _side_stream(dev) if OVERLAP_WGRAD else None
-        stats1 = P.stats_alloc((2 * Cout,), dev)
-        dWr = None
-        ev = torch.cuda.current_stream().record_event() if side is not None else None
-        gh = P.conv_rows(dO, packs[1][1], Cout, T, epilogue=L.EPI_RELU_BWD, aux=y, ep=(bn1.scale, bn1.shift, bn1.mean, bn1.rstd),
-                         stats=stats1, ntaps=kt, stride=stride, pad=pad, transposed=True)
-        if CAPTURE is not None:
-            # the kernels decide by the sign of fmaf(y, scale, shift): y * scale is exact in float64 (at most 48
-            # significant bits) and a float64 sum keeps the exact sum's sign, so this is their decision bit for bit
-            pre = y.double() * bn1.scale.double()[None, :, None, None] + bn1.shift.double()[None, :, None, None]
-            CAPTURE.append(dict(h_mask=pre > 0, out_mask=(out > 0)))
-            if CAPTURE_TENSORS:                  # diagnostics (tools/grad_budget.py): what each kernel read and wrote
-                CAPTURE[-1].update(x=x, y=y, o=o, r=r_, dout=dout, dpool=dpool, dO=dO, dR=dR, g=g, gh=gh.clone(),
-                                   bn=(bn1, bn2, bnr), relu_mask=ctx.relu_mask)
-        with _Fork(side, ev):                            # issued behind the data-gradient kernel: runs beside bn_bwd_apply
-            dWt = P.conv_wgrad(y, dO, kt, stride, pad, pro=(bn1.scale, bn1.shift))
-            if kind == "conv":
-                dWr = P.conv_wgrad(x, dR, 1, stride, 0)
-        dy, dg1, db1 = P.bn_bwd_apply(gh, y, f32(g1), bn1, stats1, training, out=gh, want_grads=True)
-        ev = torch.cuda.current_stream().record_event() if side is not None else None
+        # the partial sums of the block's parameter gradients, and the float32 copies of its bias sums, are produced by
+        # one launch at the end of the block (on one stream only: with the second stream every sum follows its own
+        # kernel at once)
+        with (P.deferred_sums(dev) if side is None else contextlib.nullcontext()):
+            dO, dR, g, stats2, statsr, dbt, dbr_f, (dg2, db2, dgr, dbetar) = P.block_out_bwd(
+                dout, out, o, r_, bn2, f32(g2), bnr, f32(gr) if kind == "conv" else None, kind == "identity" and not mask_in_dx,
+                p, seed, training, dpool=dpool, relu_mask=ctx.relu_mask, want_bn_grads=True)
 
-        add = g
-        if kind == "conv":
-            add = P.conv_rows(dR, packs[2][1], cin_p, T, ntaps=1, stride=stride, pad=0, transposed=True)
-        if mask_in_dx:
-            dx = P.gcn_fused(dy, packs[0][1], A32, cin_p, add=dout, add_mask=ctx.relu_mask)
-        else:
-            dx = P.gcn_fused(dy, packs[0][1], A32, cin_p, add=add)
-        dA = None
-        with _Fork(side, ev):
-            dWp, dbg = P.gcn_wgrad(x, dy, A32, need_bias=True)
-            dWg = dWp[:, :, :cin_true].reshape(Wg.shape)
-            if ctx.needs_input_grad[1]:
-                dA = P.gcn_agrad(x, packs[0][0], f32(bg), dy)
+            # temporal conv: weight grad (input = relu(bn1(y)) recomputed in the prologue), then data grad fused with
+            # the ReLU mask and the BN1-backward sums
+            stats1 = P.stats_alloc((2 * Cout,), dev)
+            dWr = None
+            ev = torch.cuda.current_stream().record_event() if side is not None else None
+            gh = P.conv_rows(dO, packs[1][1], Cout, T, epilogue=L.EPI_RELU_BWD, aux=y, ep=(bn1.scale, bn1.shift, bn1.mean, bn1.rstd),
+                             stats=stats1, ntaps=kt, stride=stride, pad=pad, transposed=True)
+            if CAPTURE is not None:
+                # the kernels decide by the sign of fmaf(y, scale, shift): y * scale is exact in float64 (at most 48
+                # significant bits) and a float64 sum keeps the exact sum's sign, so this is their decision bit for bit
+                pre = y.double() * bn1.scale.double()[None, :, None, None] + bn1.shift.double()[None, :, None, None]
+                CAPTURE.append(dict(h_mask=pre > 0, out_mask=(out > 0)))
+                if CAPTURE_TENSORS:                  # diagnostics (tools/grad_budget.py): what each kernel read and wrote
+                    CAPTURE[-1].update(x=x, y=y, o=o, r=r_, dout=dout, dpool=dpool, dO=dO, dR=dR, g=g, gh=gh.clone(),
+                                       bn=(bn1, bn2, bnr), relu_mask=ctx.relu_mask)
+            with _Fork(side, ev):                        # issued behind the data-gradient kernel: runs beside bn_bwd_apply
+                dWt = P.conv_wgrad(y, dO, kt, stride, pad, pro=(bn1.scale, bn1.shift))
+                if kind == "conv":
+                    dWr = P.conv_wgrad(x, dR, 1, stride, 0)
+            dy, dg1, db1 = P.bn_bwd_apply(gh, y, f32(g1), bn1, stats1, training, out=gh, want_grads=True)
+            ev = torch.cuda.current_stream().record_event() if side is not None else None
+
+            add = g
+            if kind == "conv":
+                add = P.conv_rows(dR, packs[2][1], cin_p, T, ntaps=1, stride=stride, pad=0, transposed=True)
+            if mask_in_dx:
+                dx = P.gcn_fused(dy, packs[0][1], A32, cin_p, add=dout, add_mask=ctx.relu_mask)
+            else:
+                dx = P.gcn_fused(dy, packs[0][1], A32, cin_p, add=add)
+            dA = None
+            with _Fork(side, ev):
+                dWp, dbg = P.gcn_wgrad(x, dy, A32, need_bias=True)
+                dWg = dWp[:, :, :cin_true].reshape(Wg.shape)
+                if ctx.needs_input_grad[1]:
+                    dA = P.gcn_agrad(x, packs[0][0], f32(bg), dy)
         if side is not None:
             torch.cuda.current_stream().wait_stream(side)
         if CAPTURE is not None and CAPTURE_TENSORS:

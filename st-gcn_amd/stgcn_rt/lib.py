@@ -26,6 +26,11 @@ _SIGS = {
     "stgcn_gcn_agrad": [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp],
     "stgcn_gcn_agrad_noalloc": [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "stgcn_gcn_wgrad": [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp],
+    "stgcn_conv_wgrad_deferred": [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp, _vp, _vp],
+    "stgcn_gcn_agrad_deferred": [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp, _vp, _vp],
+    "stgcn_gcn_wgrad_deferred": [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp, _vp, _vp],
+    "stgcn_sum_list_add_cast": [_vp, _vp, _vp, _sz],
+    "stgcn_sum_list_run": [_vp, _vp],
     "stgcn_bn_finalize": [_vp, _d, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _i, _i, _vp],
     "stgcn_stats_to_grads": [_vp, _vp, _vp, _i, _vp],
     "stgcn_block_out_fwd": [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _f, _u32, _vp, _vp],
@@ -50,7 +55,8 @@ _SIGS = {
 
 EXPORTS = tuple(_SIGS) + ("stgcn_arch",)
 _ERR = {1: "invalid argument", 2: "kernel launch failed", 3: "workspace too small",
-        4: "the problem exceeds the library's static scratch array"}
+        4: "the problem exceeds the library's static scratch array", 5: "the sum list is full"}
+SUM_LIST_BYTES = 1024
 
 
 def lib_path():

@@ -5,6 +5,9 @@ format (physically [B][T][V][C]); parameters stay float32 in their reference sha
 re-packed (tiny tensors) per call.  PyTorch here is plumbing: device memory, streams, autograd
 bookkeeping.  Every arithmetic step of the path is a kernel of libstgcn_hip.so.
 """
+import contextlib
+import ctypes
+
 import torch
 
 from . import lib as L
@@ -18,13 +21,14 @@ TIMING = None
 TIMING_NAMES = None
 
 
-def _launch(key, name, *args):
+def _launch(key, name, *args, entry=None):
+    """`entry`: the entry point to call when it is not `name` (a variant timed under the plain entry point's name)."""
     if TIMING is None or (TIMING_NAMES is not None and name not in TIMING_NAMES):
-        return L.call(name, *args)
+        return L.call(entry or name, *args)
     e0 = torch.cuda.Event(enable_timing=True)
     e1 = torch.cuda.Event(enable_timing=True)
     e0.record()
-    L.call(name, *args)
+    L.call(entry or name, *args)
     e1.record()
     TIMING.setdefault((name,) + tuple(key), []).append((e0, e1))
 
@@ -54,12 +58,78 @@ def pad_to(n, m):
 
 
 def workspace(device, nbytes=96 << 20):
+    """The device's partial-sum workspace, at least `nbytes` long (it only ever grows)."""
     key = (device.type, device.index)
     w = _ws.get(key)
     if w is None or w.numel() < nbytes:
         w = torch.empty(nbytes, dtype=torch.uint8, device=device)
         _ws[key] = w
     return w
+
+
+# The parameter-gradient entry points (conv_wgrad, gcn_wgrad, gcn_agrad) write partial sums into the workspace and
+# add them up with a second, small launch.  Inside `with deferred_sums(device):` the second launches are collected
+# and issued as one (a block's backward: one launch instead of three or four).  Every call is given a fresh piece of a
+# larger workspace, of the same WS_BYTES the undeferred call sees, so the partials and therefore the results are the
+# same bit for bit.
+WS_BYTES = 96 << 20
+DEFER_WS_BYTES = 4 * WS_BYTES
+_DEFER = None
+
+
+class _SumList:
+    def __init__(self, device):
+        self.device = device
+        self.buf = ctypes.create_string_buffer(L.SUM_LIST_BYTES)
+        self.count = ctypes.c_int.from_buffer(self.buf)          # the list's first field: sums waiting
+        self.used = ctypes.c_size_t(0)
+        self.off = 0
+
+    def run(self):
+        if self.count.value:
+            L.call("stgcn_sum_list_run", ctypes.addressof(self.buf), L.stream_ptr())
+        self.off = 0
+
+
+@contextlib.contextmanager
+def deferred_sums(device):
+    global _DEFER
+    if _DEFER is not None:                                       # nested: the outer scope issues the sums
+        yield _DEFER
+        return
+    _DEFER = d = _SumList(device)
+    try:
+        yield d
+        d.run()
+    finally:
+        _DEFER = None
+
+
+def to_float32(src):
+    """float32 copy of a float64 tensor of finished sums: inside deferred_sums the conversion rides in the list's
+    launch (the copy is complete once the scope has closed), otherwise it is a launch of its own."""
+    d = _DEFER
+    if d is None or d.device != src.device or not src.is_contiguous():
+        return src.float()
+    if d.count.value > 7:
+        d.run()
+    dst = torch.empty(src.shape, dtype=torch.float32, device=src.device)
+    L.call("stgcn_sum_list_add_cast", ctypes.addressof(d.buf), L.ptr(src), L.ptr(dst), src.numel())
+    return dst
+
+
+def _two_stage(key, name, device, *args):
+    """Calls `name`(*args, workspace, workspace_bytes, stream), or its _deferred form inside deferred_sums."""
+    d = _DEFER
+    if d is None or d.device != device:
+        ws = workspace(device)
+        return _launch(key, name, *args, L.ptr(ws), WS_BYTES, L.stream_ptr())
+    ws = workspace(device, DEFER_WS_BYTES)
+    if d.count.value > 6 or d.off + WS_BYTES > DEFER_WS_BYTES:   # a call adds at most two sums to a list of eight
+        d.run()
+    _launch(key, name, *args, ws.data_ptr() + d.off, WS_BYTES, ctypes.addressof(d.buf), ctypes.addressof(d.used), L.stream_ptr(),
+            entry=name + "_deferred")
+    d.off += (d.used.value + 255) // 256 * 256
 
 
 # Zero-initialised float64 statistic buffers come out of one arena that is cleared with a single fill per training
@@ -226,10 +296,10 @@ def conv_wgrad(x, dout, ntaps, stride, pad, dil=1, pro=None):
     B, Cin, Tin, V = x.shape
     Cout, Tout = dout.shape[1], dout.shape[2]
     dW = torch.empty((Cout, Cin, ntaps, 1), dtype=torch.float32, device=x.device)
-    ws = workspace(x.device)
     ps, pb = pro if pro is not None else (None, None)
-    _launch((str(x.dtype), B, Tin, Tout, V, Cin, Cout, ntaps, stride), "stgcn_conv_wgrad", L.dtype_code(x.dtype), L.ptr(x), L.ptr(dout), L.ptr(dW), L.ptr(ps), L.ptr(pb),
-           B, Tin, Tout, V, Cin, Cout, ntaps, stride, pad, dil, L.ptr(ws), ws.numel(), L.stream_ptr())
+    _two_stage((str(x.dtype), B, Tin, Tout, V, Cin, Cout, ntaps, stride), "stgcn_conv_wgrad", x.device,
+               L.dtype_code(x.dtype), L.ptr(x), L.ptr(dout), L.ptr(dW), L.ptr(ps), L.ptr(pb),
+               B, Tin, Tout, V, Cin, Cout, ntaps, stride, pad, dil)
     return dW
 
 
@@ -253,11 +323,11 @@ def gcn_agrad(x, w_packed, bias, dy):
     B, Cin, T, V = x.shape
     K, Cout = w_packed.shape[0], w_packed.shape[1]
     dA = torch.empty((K, V, V), dtype=torch.float32, device=x.device)
-    ws = workspace(x.device)
     for k0, kn in _kgroups(K):
         bk = None if bias is None else bias[k0 * Cout:(k0 + kn) * Cout]
-        _launch((str(x.dtype), B * T, V, Cin, Cout, kn), "stgcn_gcn_agrad", L.dtype_code(x.dtype), L.ptr(x), L.ptr(w_packed[k0:k0 + kn]), L.ptr(bk), L.ptr(dy), L.ptr(dA[k0:k0 + kn]),
-               B * T, V, Cin, Cout, kn, L.ptr(ws), ws.numel(), L.stream_ptr())
+        _two_stage((str(x.dtype), B * T, V, Cin, Cout, kn), "stgcn_gcn_agrad", x.device,
+                   L.dtype_code(x.dtype), L.ptr(x), L.ptr(w_packed[k0:k0 + kn]), L.ptr(bk), L.ptr(dy), L.ptr(dA[k0:k0 + kn]),
+                   B * T, V, Cin, Cout, kn)
     return dA
 
 
@@ -268,11 +338,11 @@ def gcn_wgrad(x, dy, adj, need_bias=True):
     K = adj.shape[0]
     dW = torch.empty((K, Cout, Cin), dtype=torch.float32, device=x.device)
     db = torch.empty((K * Cout,), dtype=torch.float32, device=x.device) if need_bias else None
-    ws = workspace(x.device)
     for k0, kn in _kgroups(K):
         dbk = None if db is None else db[k0 * Cout:(k0 + kn) * Cout]
-        _launch((str(x.dtype), B * T, V, Cin, Cout, kn), "stgcn_gcn_wgrad", L.dtype_code(x.dtype), L.ptr(x), L.ptr(dy), L.ptr(adj[k0:k0 + kn]), L.ptr(dW[k0:k0 + kn]), L.ptr(dbk),
-               B * T, V, Cin, Cout, kn, L.ptr(ws), ws.numel(), L.stream_ptr())
+        _two_stage((str(x.dtype), B * T, V, Cin, Cout, kn), "stgcn_gcn_wgrad", x.device,
+                   L.dtype_code(x.dtype), L.ptr(x), L.ptr(dy), L.ptr(adj[k0:k0 + kn]), L.ptr(dW[k0:k0 + kn]), L.ptr(dbk),
+                   B * T, V, Cin, Cout, kn)
     return dW, db
 
 
@@ -345,7 +415,7 @@ def block_out_bwd(dout, out, o, r, bn2, gamma2, bnr, gammar, want_g, drop_p, see
     _launch((str(o.dtype), 1, rows, Cc, has_r, want_g), "stgcn_block_out_bwd", *args)
     # the bias sums leave this function (they become .grad of the conv biases): float32 memory of their own, not views
     # of the statistics arena, which the next training forward clears
-    dbf = acc[4:6].float()
+    dbf = to_float32(acc[4:6])
     dbo, dbr = dbf[0], dbf[1]
     res = (dO, dR, g, stats2, (statsr if has_r else None), dbo, (dbr if has_r else None))
     if want_bn_grads:

@@ -44,6 +44,29 @@ def rel(a, b):
     return ((a - b).abs().max() / (b.abs().max() + 1e-30)).item()
 
 
+def conv_paths(dtype, width):
+    """The launch paths a temporal-convolution test runs: the default choice and, for bf16 with 128 / 256 output
+    channels, the whole-width-tile kernel forced onto the small shape (by default it only takes grids that fill the
+    chip; the full-size tests reach it that way)."""
+    import contextlib
+    import os
+
+    @contextlib.contextmanager
+    def env(force):
+        old = os.environ.pop("STGCN_CONV_WIDE_ANY_GRID", None)
+        if force:
+            os.environ["STGCN_CONV_WIDE_ANY_GRID"] = "1"
+        try:
+            yield
+        finally:
+            os.environ.pop("STGCN_CONV_WIDE_ANY_GRID", None)
+            if old is not None:
+                os.environ["STGCN_CONV_WIDE_ANY_GRID"] = old
+
+    forced = dtype == torch.bfloat16 and width in (128, 256)
+    return [env(f) for f in ((False, True) if forced else (False,))]
+
+
 def test_probe_tr16(rt):
     from stgcn_rt import lib as L
     out = torch.zeros(64 * 8, dtype=torch.int16, device=DEV)
@@ -105,18 +128,20 @@ def test_conv_rows_forward(rt, case, dtype):
         h = q(h, dtype)                       # the kernel rounds the activated input before the MFMA
     ref = O.tconv_forward(h, W, b, stride, pad)
     To = ref.shape[2]
-    stats = torch.zeros(2 * Cout, dtype=torch.float64, device=DEV)
     wp = rt.pack_conv_w(W[..., None].to(DEV).float(), dtype)
-    out = rt.conv_rows(to_dev(x, dtype), wp, Cout, To, bias=b.to(DEV).float(),
-                       pro=(sc.to(DEV).float(), sh.to(DEV).float()) if pro else None, stats=stats,
-                       ntaps=kt, stride=stride, pad=pad)
-    torch.cuda.synchronize()
-    assert out.shape == ref.shape
-    assert rel(out, ref) < TOL[dtype]
-    s = stats.cpu()
-    n = B * To * V
-    assert rel(s[:Cout] / n, ref.mean(dim=(0, 2, 3))) < TOL[dtype] * 2 + 1e-6
-    assert rel(s[Cout:] / n, (ref ** 2).mean(dim=(0, 2, 3))) < TOL[dtype] * 2
+    for path in conv_paths(dtype, Cout):
+        with path:
+            stats = torch.zeros(2 * Cout, dtype=torch.float64, device=DEV)
+            out = rt.conv_rows(to_dev(x, dtype), wp, Cout, To, bias=b.to(DEV).float(),
+                               pro=(sc.to(DEV).float(), sh.to(DEV).float()) if pro else None, stats=stats,
+                               ntaps=kt, stride=stride, pad=pad)
+            torch.cuda.synchronize()
+        assert out.shape == ref.shape
+        assert rel(out, ref) < TOL[dtype]
+        s = stats.cpu()
+        n = B * To * V
+        assert rel(s[:Cout] / n, ref.mean(dim=(0, 2, 3))) < TOL[dtype] * 2 + 1e-6
+        assert rel(s[Cout:] / n, (ref ** 2).mean(dim=(0, 2, 3))) < TOL[dtype] * 2
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
@@ -139,12 +164,14 @@ def test_conv_rows_add_relu_epilogue(rt, case, with_res, dtype):
     res = q(t64(tuple(o.shape), 46), dtype) if with_res else None
     ref = torch.clamp_min(o + (res if with_res else 0), 0)
     wp = rt.pack_conv_w(W[..., None].to(DEV).float(), dtype)
-    out = rt.conv_rows(to_dev(x, dtype), wp, Cout, o.shape[2], bias=b.to(DEV).float(),
-                       pro=(sc.to(DEV).float(), sh.to(DEV).float()) if pro else None, epilogue=L.EPI_ADD_RELU,
-                       aux=to_dev(res, dtype) if with_res else None, ntaps=kt, stride=stride, pad=pad)
-    torch.cuda.synchronize()
-    assert out.shape == ref.shape and float(out.min()) >= 0
-    assert rel(out, ref) < TOL[dtype]
+    for path in conv_paths(dtype, Cout):
+        with path:
+            out = rt.conv_rows(to_dev(x, dtype), wp, Cout, o.shape[2], bias=b.to(DEV).float(),
+                               pro=(sc.to(DEV).float(), sh.to(DEV).float()) if pro else None, epilogue=L.EPI_ADD_RELU,
+                               aux=to_dev(res, dtype) if with_res else None, ntaps=kt, stride=stride, pad=pad)
+            torch.cuda.synchronize()
+        assert out.shape == ref.shape and float(out.min()) >= 0
+        assert rel(out, ref) < TOL[dtype]
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
@@ -163,8 +190,11 @@ def test_conv_rows_transposed_and_wgrad(rt, case, dtype):
     dh, dW, _ = O.tconv_backward(h, W, do, stride, pad)
     # data gradient through the transposed form
     wt = rt.pack_conv_wt(W[..., None].to(DEV).float(), dtype)
-    got = rt.conv_rows(to_dev(do, dtype), wt, Cin, T, ntaps=kt, stride=stride, pad=pad, transposed=True)
-    assert rel(got, dh) < TOL[dtype]
+    for path in conv_paths(dtype, Cin):
+        with path:
+            got = rt.conv_rows(to_dev(do, dtype), wt, Cin, T, ntaps=kt, stride=stride, pad=pad, transposed=True)
+            torch.cuda.synchronize()
+        assert rel(got, dh) < TOL[dtype]
     # weight gradient
     gW = rt.conv_wgrad(to_dev(x, dtype), to_dev(do, dtype), kt, stride, pad,
                        pro=(sc.to(DEV).float(), sh.to(DEV).float()) if pro else None)
@@ -189,15 +219,18 @@ def test_conv_rows_relu_bwd_epilogue(rt, shape, dtype):
     dh, _, _ = O.tconv_backward(torch.clamp_min(pre, 0), W, do, 1, 4)
     g = dh * (pre > 0)
     xhat = (y - sh4(mean)) * sh4(rstd)
-    stats = torch.zeros(2 * Cc, dtype=torch.float64, device=DEV)
     f = lambda v: v.to(DEV).float().contiguous()
-    got = rt.conv_rows(to_dev(do, dtype), rt.pack_conv_wt(W[..., None].to(DEV).float(), dtype), Cc, T,
-                       epilogue=L.EPI_RELU_BWD, aux=to_dev(y, dtype), ep=(f(scale), f(shift), f(mean), f(rstd)),
-                       stats=stats, ntaps=kt, stride=1, pad=4, transposed=True)
-    assert rel(got, g) < TOL[dtype]
-    s = stats.cpu()
-    assert rel(s[:Cc], g.sum(dim=(0, 2, 3))) < TOL[dtype] * 3
-    assert rel(s[Cc:], (g * xhat).sum(dim=(0, 2, 3))) < TOL[dtype] * 3
+    for path in conv_paths(dtype, Cc):
+        with path:
+            stats = torch.zeros(2 * Cc, dtype=torch.float64, device=DEV)
+            got = rt.conv_rows(to_dev(do, dtype), rt.pack_conv_wt(W[..., None].to(DEV).float(), dtype), Cc, T,
+                               epilogue=L.EPI_RELU_BWD, aux=to_dev(y, dtype), ep=(f(scale), f(shift), f(mean), f(rstd)),
+                               stats=stats, ntaps=kt, stride=1, pad=4, transposed=True)
+            torch.cuda.synchronize()
+        assert rel(got, g) < TOL[dtype]
+        s = stats.cpu()
+        assert rel(s[:Cc], g.sum(dim=(0, 2, 3))) < TOL[dtype] * 3
+        assert rel(s[Cc:], (g * xhat).sum(dim=(0, 2, 3))) < TOL[dtype] * 3
 
 
 GCN_DIRECT = [
@@ -493,3 +526,58 @@ def test_block_out_bwd_pooled_gradient(rt, dtype):
     tol = TOL[dtype]
     assert rel(dO, do_ref) < tol * 2
     assert rel(stats2.cpu()[1], dg_ref) < tol * 2 and rel(stats2.cpu()[0], db_ref) < tol * 2
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("Cc,V,T,stride", [(64, 25, 40, 1), (128, 18, 37, 2), (256, 25, 12, 1)], ids=lambda v: str(v))
+def test_deferred_sums_equal_immediate_sums(rt, Cc, V, T, stride, dtype):
+    """The _deferred entry points plus ONE stgcn_sum_list_run give the gradients of the two-stage entry points bit for
+    bit (same partials, same order of additions), whatever else waits on the list; the float64 -> float32 copy that
+    rides on the list equals .float(); a ninth entry is refused with status 5 and leaves the list as it was."""
+    import ctypes
+    from stgcn_rt import lib as L
+    B, K = 3, 3
+    To = (T - 1) // stride + 1
+    x = to_dev(t64((B, Cc, T, V), 9100), dtype)
+    dO = to_dev(t64((B, Cc, To, V), 9101), dtype)
+    dy = to_dev(t64((B, Cc, T, V), 9102), dtype)
+    sc = t64((Cc,), 9103, 0.5, 1.5).float().to(DEV)
+    sh = t64((Cc,), 9104, -0.2, 0.2).float().to(DEV)
+    adj = t64((K, V, V), 9105, 0.0, 0.3).float().to(DEV)
+    Wg = t64((K * Cc, Cc, 1, 1), 9106, -0.1, 0.1).float().to(DEV)
+    bg = t64((K * Cc,), 9107, -0.1, 0.1).float().to(DEV)
+    wp = rt.pack_gcn_w(Wg, K, Cc, dtype)
+    sums64 = torch.tensor(O.det_uniform((2, Cc), 9108, -1e3, 1e3), dtype=torch.float64, device=DEV)
+
+    def run_all():
+        dWt = rt.conv_wgrad(x, dO, 9, stride, 4, pro=(sc, sh))
+        dWr = rt.conv_wgrad(x, dO, 1, stride, 0)
+        dWp, dbp = rt.gcn_wgrad(x, dy, adj)
+        dA = rt.gcn_agrad(x, wp, bg, dy)
+        f = rt.to_float32(sums64)
+        return [dWt, dWr, dWp, dbp, dA, f]
+
+    want = run_all()
+    with rt.deferred_sums(torch.device(DEV)) as d:
+        got = run_all()
+        assert d.count.value == (6 if dtype == torch.float32 else 5)       # the float32 graph-conv form sums W and b apart
+        assert d.off > 0
+    torch.cuda.synchronize()
+    assert d.count.value == 0
+    for a, b in zip(got, want):
+        assert torch.equal(a, b)
+    assert torch.equal(want[5], sums64.float())
+
+    # a full list refuses the next entry and keeps its eight
+    buf = ctypes.create_string_buffer(L.SUM_LIST_BYTES)
+    dst = torch.zeros((9, 2, Cc), dtype=torch.float32, device=DEV)
+    for i in range(8):
+        L.call("stgcn_sum_list_add_cast", ctypes.addressof(buf), sums64.data_ptr(), dst[i].data_ptr(), sums64.numel())
+    rc = L.load().stgcn_sum_list_add_cast(ctypes.addressof(buf), sums64.data_ptr(), dst[8].data_ptr(), sums64.numel())
+    assert rc == 5 and ctypes.c_int.from_buffer(buf).value == 8
+    L.call("stgcn_sum_list_run", ctypes.addressof(buf), L.stream_ptr())
+    torch.cuda.synchronize()
+    assert ctypes.c_int.from_buffer(buf).value == 0
+    for i in range(8):
+        assert torch.equal(dst[i], sums64.float())
+    assert not dst[8].any()

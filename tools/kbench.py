@@ -125,8 +125,11 @@ def main():
     ap.add_argument("--lib", default=None, help="alternative build of libstgcn_hip.so (A/B timing on one device)")
     ap.add_argument("--rotate", type=int, default=1, help="cycle through this many independent sets of tensors (a training step never "
                     "re-reads what the caches, the memory-side cache included, still hold from the launch before)")
+    ap.add_argument("--batch", type=int, default=128, help="samples B = clips x persons (128: the 64-clip step; 16: the 8-clip step)")
     ap.add_argument("--print-key", action="store_true", help="also print the launch's timing key (entry point + shape), as bench.py's tables name it")
     a = ap.parse_args()
+    global B
+    B = a.batch
     dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     if a.lib:
         L._LIB_PATH = os.path.abspath(a.lib)

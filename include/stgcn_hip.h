@@ -149,6 +149,22 @@ int stgcn_block_out_fwd(int dtype, const void* o, const void* res, void* out, vo
                         const float* scale2, const float* shift2, const float* res_scale, const float* res_shift,
                         size_t rows, int C, float drop_p, uint32_t seed, const uint32_t* seed_step, void* stream);
 
+/* stgcn_block_out_fwd for train mode with the two BatchNorms finished inside the launch: bn2 (of o) and, when
+ * bnr_stats is given, the residual branch's BatchNorm (of res) arrive as the double sums [sum[C], sum of squares[C]] that
+ * the producing convolutions gathered over `rows` rows.  Every workgroup derives scale / shift from the sums with the
+ * arithmetic of stgcn_bn_finalize (same floats); workgroup 0 also writes mean, rstd, scale, shift to bn2_out / bnr_out
+ * (float[4][C], read by stgcn_block_out_bwd) and advances the running statistics (momentum, unbiased variance; either
+ * pair may be null).  One launch instead of three.
+ * Replaces: the same operators as stgcn_block_out_fwd plus the statistics half of the two nn.BatchNorm2d
+ * (net/st_gcn.py:169, 186). */
+int stgcn_block_out_fwd_bn(int dtype, const void* o, const void* res, void* out, void* relu_mask,
+                           const double* bn2_stats, const float* gamma2, const float* beta2,
+                           float* running_mean2, float* running_var2, float* bn2_out,
+                           const double* bnr_stats, const float* gammar, const float* betar,
+                           float* running_meanr, float* running_varr, float* bnr_out,
+                           float momentum, float eps,
+                           size_t rows, int C, float drop_p, uint32_t seed, const uint32_t* seed_step, void* stream);
+
 /* Backward of the stage above.  pass 0: per-channel sums (stats2, statsr).  pass 1: dO (BatchNorm backward of the
  * main branch), dR (same for a conv residual), g (= masked incoming gradient, for an identity residual), the
  * bias gradients of the two convolutions (dbias_*: double[C] sums accumulated with atomics, zeroed by the caller) and,

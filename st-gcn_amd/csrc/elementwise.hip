@@ -77,30 +77,44 @@ __device__ __forceinline__ void wide_channel_reduce(float (*sums)[ET<T>::VEC], c
 
 // ------------------------------------------------------------------------------------------
 // BatchNorm parameter finalisation (tiny)
+// Batch statistics -> the coefficients of one channel.  One definition for the finalize kernel and for the kernels that
+// fold it into their prologue: both must arrive at the same floats.
+struct BnCoeff { float mean, rstd, scale, shift, unbiased_var; };
+__device__ __forceinline__ BnCoeff bn_coeff_from_sums(double s1, double s2, double count, float gamma, float beta, float eps) {
+    const double m = s1 / count;
+    double v = s2 / count - m * m;
+    if (v < 0) v = 0;
+    BnCoeff k;
+    k.mean = (float)m;
+    k.unbiased_var = (float)(count > 1 ? v * (count / (count - 1)) : v);
+    k.rstd = 1.0f / sqrtf((float)v + eps);
+    k.scale = gamma * k.rstd;
+    k.shift = fmaf(-k.mean, k.scale, beta);
+    return k;
+}
+
 __global__ void bn_finalize_kernel(const double* stats, double count, const float* gamma, const float* beta,
                                    float* rmean, float* rvar, float momentum, float eps,
                                    float* mean, float* rstd, float* scale, float* shift, int C, int training) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    float mu, var;
+    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    BnCoeff k;
     if (training) {
-        const double m = stats[c] / count;
-        double v = stats[C + c] / count - m * m;
-        if (v < 0) v = 0;
-        mu = (float)m; var = (float)v;
+        k = bn_coeff_from_sums(stats[c], stats[C + c], count, g, b, eps);
         if (rmean) {
-            const double unb = count > 1 ? v * (count / (count - 1)) : v;
-            rmean[c] = (1.f - momentum) * rmean[c] + momentum * mu;
-            rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
+            rmean[c] = (1.f - momentum) * rmean[c] + momentum * k.mean;
+            rvar[c] = (1.f - momentum) * rvar[c] + momentum * k.unbiased_var;
         }
     } else {
-        mu = rmean[c]; var = rvar[c];
+        k.mean = rmean[c];
+        k.rstd = 1.0f / sqrtf(rvar[c] + eps);
+        k.scale = g * k.rstd;
+        k.shift = fmaf(-k.mean, k.scale, b);
     }
-    const float rs = 1.0f / sqrtf(var + eps);
-    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
-    mean[c] = mu; rstd[c] = rs;
-    scale[c] = g * rs;
-    shift[c] = b - mu * g * rs;
+    mean[c] = k.mean; rstd[c] = k.rstd;
+    scale[c] = k.scale;
+    shift[c] = k.shift;
 }
 
 extern "C" int stgcn_bn_finalize(const double* stats, double count, const float* gamma, const float* beta,
@@ -129,9 +143,16 @@ extern "C" int stgcn_stats_to_grads(const double* stats, float* dgamma, float* d
 
 // ------------------------------------------------------------------------------------------
 // Block output stage:  out = relu( (s2*o + b2) * keep/(1-p) + res' ),  res' = sr*res + br | res | 0
+// A BatchNorm whose statistics the output stage finishes itself (train mode): the sums its producer gathered, the
+// parameters, where the coefficients go for the backward, the running statistics to advance.  stats == null: not used.
+struct BnFromSums {
+    const double* stats; const float* gamma; const float* beta; float* rmean; float* rvar;
+    float* mean; float* rstd; float* scale; float* shift;
+};
 struct BlockOutArgs {
     const void* o; const void* res; void* out;
     const float* s2; const float* b2; const float* sr; const float* br;
+    BnFromSums f2, fr; double count; float momentum, eps;
     uint16_t* mask;      // optional: two bytes per 16-byte piece: bit j = (element j > 0), bit 8+j = (element j kept by dropout)
     size_t rows; int C; uint32_t seed, thr; float keep_scale;
     const uint32_t* seed_step;   // optional device counter mixed into the seed (see stgcn_block_out_fwd)
@@ -144,11 +165,42 @@ __global__ __launch_bounds__(NT) void block_out_fwd_kernel(BlockOutArgs a) {
     if (!m.active) return;
     if (a.thr && a.seed_step) a.seed += *a.seed_step * STGCN_SEED_STEP_MUL;
     float s2[VEC], b2[VEC], sr[VEC], br[VEC];
+    if (a.f2.stats) {
+        // every thread derives the coefficients of its channels from the sums (a few dozen operations against the rows
+        // it streams); the threads of workgroup 0 that own row lane 0 also publish them and advance the running statistics
+        const bool publish = blockIdx.x == 0 && m.rl == 0;
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) {
-        const int c = m.cv * VEC + j;
-        s2[j] = a.s2[c]; b2[j] = a.b2[c];
-        sr[j] = a.sr ? a.sr[c] : 1.f; br[j] = a.br ? a.br[c] : 0.f;
+        for (int j = 0; j < VEC; ++j) {
+            const int c = m.cv * VEC + j;
+            const BnCoeff k = bn_coeff_from_sums(a.f2.stats[c], a.f2.stats[a.C + c], a.count, a.f2.gamma[c], a.f2.beta[c], a.eps);
+            s2[j] = k.scale; b2[j] = k.shift;
+            if (publish) {
+                a.f2.mean[c] = k.mean; a.f2.rstd[c] = k.rstd; a.f2.scale[c] = k.scale; a.f2.shift[c] = k.shift;
+                if (a.f2.rmean) {
+                    a.f2.rmean[c] = (1.f - a.momentum) * a.f2.rmean[c] + a.momentum * k.mean;
+                    a.f2.rvar[c] = (1.f - a.momentum) * a.f2.rvar[c] + a.momentum * k.unbiased_var;
+                }
+            }
+            sr[j] = 1.f; br[j] = 0.f;
+            if (a.fr.stats) {
+                const BnCoeff q = bn_coeff_from_sums(a.fr.stats[c], a.fr.stats[a.C + c], a.count, a.fr.gamma[c], a.fr.beta[c], a.eps);
+                sr[j] = q.scale; br[j] = q.shift;
+                if (publish) {
+                    a.fr.mean[c] = q.mean; a.fr.rstd[c] = q.rstd; a.fr.scale[c] = q.scale; a.fr.shift[c] = q.shift;
+                    if (a.fr.rmean) {
+                        a.fr.rmean[c] = (1.f - a.momentum) * a.fr.rmean[c] + a.momentum * q.mean;
+                        a.fr.rvar[c] = (1.f - a.momentum) * a.fr.rvar[c] + a.momentum * q.unbiased_var;
+                    }
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            const int c = m.cv * VEC + j;
+            s2[j] = a.s2[c]; b2[j] = a.b2[c];
+            sr[j] = a.sr ? a.sr[c] : 1.f; br[j] = a.br ? a.br[c] : 0.f;
+        }
     }
     for (size_t row = (size_t)blockIdx.x * m.rpi + m.rl; row < a.rows; row += (size_t)gridDim.x * m.rpi) {
         const size_t off = row * a.C + m.cv * VEC;
@@ -197,26 +249,56 @@ static inline uint32_t drop_thr(float p) {
     return (uint32_t)t;
 }
 
-extern "C" int stgcn_block_out_fwd(int dtype, const void* o, const void* res, void* out, void* relu_mask,
-                                   const float* scale2, const float* shift2, const float* res_scale, const float* res_shift,
-                                   size_t rows, int C, float drop_p, uint32_t seed, const uint32_t* seed_step, void* stream) {
-    if (!o || !out || !scale2 || !shift2 || drop_p < 0.f || drop_p >= 1.f) return STGCN_ERR_ARG;
-    BlockOutArgs a;
-    a.seed_step = seed_step;
-    a.o = o; a.res = res; a.out = out; a.mask = (uint16_t*)relu_mask; a.s2 = scale2; a.b2 = shift2; a.sr = res_scale; a.br = res_shift;
-    a.rows = rows; a.C = C; a.seed = seed; a.thr = drop_thr(drop_p); a.keep_scale = 1.f / (1.f - drop_p);
+static int block_out_fwd_launch(int dtype, BlockOutArgs& a, float drop_p, hipStream_t stream) {
+    const size_t rows = a.rows; const int C = a.C;
+    a.thr = drop_thr(drop_p); a.keep_scale = 1.f / (1.f - drop_p);
     if (dtype == STGCN_BF16) {
         if (!ew_ok<bf16>(C)) return STGCN_ERR_ARG;
         const int cvs = C / ET<bf16>::VEC;
         if (cvs <= 64 && (cvs & (cvs - 1)) == 0)         // as bn_bwd_apply: 512 workgroups of 512 threads (1-2 % here)
-            hipLaunchKernelGGL((block_out_fwd_kernel<bf16, 512>), dim3(ew_grid(rows, 512 / cvs, 512)), dim3(512), 0, (hipStream_t)stream, a);
+            hipLaunchKernelGGL((block_out_fwd_kernel<bf16, 512>), dim3(ew_grid(rows, 512 / cvs, 512)), dim3(512), 0, stream, a);
         else
-            hipLaunchKernelGGL((block_out_fwd_kernel<bf16, 256>), dim3(ew_grid(rows, ew_rpi<bf16>(C))), dim3(256), 0, (hipStream_t)stream, a);
+            hipLaunchKernelGGL((block_out_fwd_kernel<bf16, 256>), dim3(ew_grid(rows, ew_rpi<bf16>(C))), dim3(256), 0, stream, a);
     } else if (dtype == STGCN_F32) {
         if (!ew_ok<float>(C)) return STGCN_ERR_ARG;
-        hipLaunchKernelGGL((block_out_fwd_kernel<float, 256>), dim3(ew_grid(rows, ew_rpi<float>(C))), dim3(256), 0, (hipStream_t)stream, a);
+        hipLaunchKernelGGL((block_out_fwd_kernel<float, 256>), dim3(ew_grid(rows, ew_rpi<float>(C))), dim3(256), 0, stream, a);
     } else return STGCN_ERR_ARG;
     return hipGetLastError() == hipSuccess ? STGCN_OK : STGCN_ERR_LAUNCH;
+}
+
+extern "C" int stgcn_block_out_fwd(int dtype, const void* o, const void* res, void* out, void* relu_mask,
+                                   const float* scale2, const float* shift2, const float* res_scale, const float* res_shift,
+                                   size_t rows, int C, float drop_p, uint32_t seed, const uint32_t* seed_step, void* stream) {
+    if (!o || !out || !scale2 || !shift2 || drop_p < 0.f || drop_p >= 1.f) return STGCN_ERR_ARG;
+    BlockOutArgs a{};
+    a.seed_step = seed_step;
+    a.o = o; a.res = res; a.out = out; a.mask = (uint16_t*)relu_mask; a.s2 = scale2; a.b2 = shift2; a.sr = res_scale; a.br = res_shift;
+    a.rows = rows; a.C = C; a.seed = seed;
+    return block_out_fwd_launch(dtype, a, drop_p, (hipStream_t)stream);
+}
+
+// The train-mode output stage with its BatchNorms finished in the same launch: bn2 (and, with bnr_stats, the residual
+// branch's BatchNorm) arrive as the double sums [sum, sum of squares] their convolutions gathered over `rows` rows.
+// Every workgroup derives scale and shift from the sums; workgroup 0 writes mean / rstd / scale / shift to bn*_out
+// (float[4][C], for the backward) and advances the running statistics (either pair may be null).
+extern "C" int stgcn_block_out_fwd_bn(int dtype, const void* o, const void* res, void* out, void* relu_mask,
+                                      const double* bn2_stats, const float* gamma2, const float* beta2,
+                                      float* running_mean2, float* running_var2, float* bn2_out,
+                                      const double* bnr_stats, const float* gammar, const float* betar,
+                                      float* running_meanr, float* running_varr, float* bnr_out,
+                                      float momentum, float eps,
+                                      size_t rows, int C, float drop_p, uint32_t seed, const uint32_t* seed_step, void* stream) {
+    if (!o || !out || !bn2_stats || !gamma2 || !beta2 || !bn2_out || rows == 0 || drop_p < 0.f || drop_p >= 1.f) return STGCN_ERR_ARG;
+    if ((running_mean2 == nullptr) != (running_var2 == nullptr)) return STGCN_ERR_ARG;
+    if (bnr_stats && (!res || !gammar || !betar || !bnr_out || (running_meanr == nullptr) != (running_varr == nullptr))) return STGCN_ERR_ARG;
+    BlockOutArgs a{};
+    a.seed_step = seed_step;
+    a.o = o; a.res = res; a.out = out; a.mask = (uint16_t*)relu_mask;
+    a.f2 = BnFromSums{bn2_stats, gamma2, beta2, running_mean2, running_var2, bn2_out, bn2_out + C, bn2_out + 2 * C, bn2_out + 3 * C};
+    if (bnr_stats) a.fr = BnFromSums{bnr_stats, gammar, betar, running_meanr, running_varr, bnr_out, bnr_out + C, bnr_out + 2 * C, bnr_out + 3 * C};
+    a.count = (double)rows; a.momentum = momentum; a.eps = eps;
+    a.rows = rows; a.C = C; a.seed = seed;
+    return block_out_fwd_launch(dtype, a, drop_p, (hipStream_t)stream);
 }
 
 // Backward of the output stage, pass 1: per-channel sums

@@ -27,6 +27,9 @@ CAPTURE_TENSORS = False
 # because kernels that share the device stretch each other and per-kernel durations (profiles, the benchmark's
 # roofline record) stop describing the kernels.
 OVERLAP_WGRAD = os.environ.get("STGCN_OVERLAP_WGRAD", "0") == "1"
+# Debugging aid (STGCN_BN_LAUNCHES=1): BN2 and the residual BatchNorm finished by launches of their own (bn_finalize)
+# instead of inside the output stage's launch.
+BN_LAUNCHES = os.environ.get("STGCN_BN_LAUNCHES", "0") == "1"
 _SIDE = {}
 
 
@@ -208,19 +211,27 @@ class StGcnBlockFn(torch.autograd.Function):
 
         o = P.conv_rows(y, packs[1][0], Cout, To, bias=f32(bt), pro=(bn1.scale, bn1.shift), stats=stats[1] if training else None,
                         ntaps=kt, stride=stride, pad=pad)
-        bn2 = P.bn_finalize(stats[1] if training else None, B * To * V, f32(g2), f32(b2), rm2, rv2, training)
+        # train mode: BN2 and the residual branch's BatchNorm are finished inside the output stage's launch (it derives
+        # their coefficients from the convolutions' sums); eval mode reads the running statistics with bn_finalize
+        fold = training and not BN_LAUNCHES
+        bn2 = None if fold else P.bn_finalize(stats[1] if training else None, B * To * V, f32(g2), f32(b2), rm2, rv2, training)
 
         r, bnr = None, None
         if kind == "conv":
             r = P.conv_rows(x, packs[2][0], Cout, To, bias=f32(br), stats=stats[2] if training else None, ntaps=1, stride=stride, pad=0)
-            bnr = P.bn_finalize(stats[2] if training else None, B * To * V, f32(gr), f32(betar), rmr, rvr, training)
+            if not fold:
+                bnr = P.bn_finalize(stats[2] if training else None, B * To * V, f32(gr), f32(betar), rmr, rvr, training)
             res = r
         elif kind == "identity":
             res = x
         else:
             res = None
         p = drop_p                                      # already 0 when the Dropout module is in eval mode
-        if training or p > 0:
+        if fold:
+            out, relu_mask, bn2, bnr = P.block_out_fwd_bn(o, res, stats[1], f32(g2), f32(b2), rm2, rv2,
+                                                          stats[2] if kind == "conv" else None, f32(gr) if kind == "conv" else None,
+                                                          f32(betar) if kind == "conv" else None, rmr, rvr, p, seed, seed_step=seed_step)
+        elif training or p > 0:
             out, relu_mask = P.block_out_fwd(o, res, bn2, bnr, p, seed, want_mask=True, seed_step=seed_step)
         else:
             out, relu_mask = P.block_out_fwd(o, res, bn2, bnr, p, seed), None

@@ -9,7 +9,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libstgcn_hip.so")
+_LIB_PATH = os.environ.get("STGCN_LIB") or os.path.join(_HERE, "libstgcn_hip.so")     # STGCN_LIB: another build (A/B runs)
 
 F32, BF16 = 0, 1
 EPI_PLAIN, EPI_RELU_BWD, EPI_ADD_RELU = 0, 1, 2
@@ -34,6 +34,8 @@ _SIGS = {
     "stgcn_bn_finalize": [_vp, _d, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _i, _i, _vp],
     "stgcn_stats_to_grads": [_vp, _vp, _vp, _i, _vp],
     "stgcn_block_out_fwd": [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _f, _u32, _vp, _vp],
+    "stgcn_block_out_fwd_bn": [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f,
+                               _sz, _i, _f, _u32, _vp, _vp],
     "stgcn_block_out_bwd": [_i, _i, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                             _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _f, _u32, _d, _i, _vp],
     "stgcn_bn_bwd_apply": [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _d, _vp, _vp, _sz, _i, _i, _vp],

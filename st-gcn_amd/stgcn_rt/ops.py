@@ -387,6 +387,24 @@ def block_out_fwd(o, res, bn2, bnr, drop_p, seed, want_mask=False, seed_step=Non
     return (out, mask) if want_mask else out
 
 
+def block_out_fwd_bn(o, res, stats2, gamma2, beta2, rm2, rv2, statsr, gammar, betar, rmr, rvr, drop_p, seed, seed_step=None,
+                     momentum=0.1, eps=1e-5):
+    """Train-mode output stage with its BatchNorms finished in the launch: stats2 / statsr are the double sums
+    [2*C] of o / res (statsr None: res, if any, is added as it is).  -> out, mask, bn2, bnr (BnParams or None)."""
+    B, Cc, T, V = o.shape
+    out = new_act(B, Cc, T, V, o.dtype, o.device)
+    mask = torch.empty((B * T * V * Cc * o.element_size() // 16,), dtype=torch.int16, device=o.device)
+    bn2 = BnParams(Cc, o.device)
+    bnr = BnParams(Cc, o.device) if statsr is not None else None
+    has_r = statsr is not None
+    _launch((str(o.dtype), B * T * V, Cc, res is not None, has_r), "stgcn_block_out_fwd", L.dtype_code(o.dtype), L.ptr(o), L.ptr(res), L.ptr(out), L.ptr(mask),
+            L.ptr(stats2), L.ptr(gamma2), L.ptr(beta2), L.ptr(rm2), L.ptr(rv2), L.ptr(bn2.mean),
+            L.ptr(statsr), L.ptr(gammar) if has_r else None, L.ptr(betar) if has_r else None, L.ptr(rmr) if has_r else None,
+            L.ptr(rvr) if has_r else None, L.ptr(bnr.mean) if has_r else None, float(momentum), float(eps),
+            B * T * V, Cc, float(drop_p), int(seed) & 0xFFFFFFFF, L.ptr(seed_step), L.stream_ptr(), entry="stgcn_block_out_fwd_bn")
+    return out, mask, bn2, bnr
+
+
 def block_out_bwd(dout, out, o, r, bn2, gamma2, bnr, gammar, want_g, drop_p, seed, training, dpool=None, relu_mask=None,
                   want_bn_grads=False):
     """-> dO, dR (or None), g (or None), stats2 [2,C] (sum gd, sum gd*ohat), statsr, dbias_o, dbias_r (float32 [C]);

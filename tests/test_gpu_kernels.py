@@ -581,3 +581,46 @@ def test_deferred_sums_equal_immediate_sums(rt, Cc, V, T, stride, dtype):
     for i in range(8):
         assert torch.equal(dst[i], sums64.float())
     assert not dst[8].any()
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("Cc,shape,with_r", [(64, (2, 20, 25), False), (128, (3, 19, 18), True), (256, (2, 5, 25), True), (96, (1, 7, 25), False)],
+                         ids=lambda v: str(v))
+def test_block_out_fwd_with_batchnorm_in_the_launch(rt, Cc, shape, with_r, dtype):
+    """stgcn_block_out_fwd_bn (coefficients derived from the sums inside the launch) against stgcn_bn_finalize followed
+    by stgcn_block_out_fwd: same output, same mask, same mean / rstd / scale / shift and running statistics, bit for bit."""
+    B, T, V = shape
+    rows = B * T * V
+    o = to_dev(t64((B, Cc, T, V), 9301, -2, 2), dtype)
+    res = to_dev(t64((B, Cc, T, V), 9302, -2, 2), dtype)
+    f = lambda tag, lo, hi: t64((Cc,), tag, lo, hi).float().to(DEV)
+    g2, b2, gr, br = f(9303, 0.5, 1.5), f(9304, -0.3, 0.3), f(9305, 0.5, 1.5), f(9306, -0.3, 0.3)
+
+    def sums(x):
+        x64 = x.double()
+        return torch.stack([x64.sum(dim=(0, 2, 3)), (x64 * x64).sum(dim=(0, 2, 3))]).contiguous()
+
+    st2, str_ = sums(o), sums(res)
+    run = lambda: [f(9307, -0.1, 0.1), f(9308, 0.5, 1.5), f(9309, -0.1, 0.1), f(9310, 0.5, 1.5)]
+    rm2, rv2, rmr, rvr = run()
+    bn2 = rt.bn_finalize(st2.reshape(-1), rows, g2, b2, rm2, rv2, True)
+    bnr = rt.bn_finalize(str_.reshape(-1), rows, gr, br, rmr, rvr, True) if with_r else None
+    want, want_mask = rt.block_out_fwd(o, res, bn2, bnr, 0.5, 77, want_mask=True)
+    qm2, qv2, qmr, qvr = run()
+    got, got_mask, cn2, cnr = rt.block_out_fwd_bn(o, res, st2.reshape(-1), g2, b2, qm2, qv2,
+                                                  str_.reshape(-1) if with_r else None, gr if with_r else None, br if with_r else None,
+                                                  qmr if with_r else None, qvr if with_r else None, 0.5, 77)
+    torch.cuda.synchronize()
+    assert torch.equal(got, want) and torch.equal(got_mask, want_mask)
+    for a, b in ((cn2, bn2), (cnr, bnr)):
+        if b is not None:
+            for name in ("mean", "rstd", "scale", "shift"):
+                assert torch.equal(getattr(a, name), getattr(b, name)), name
+    assert torch.equal(qm2, rm2) and torch.equal(qv2, rv2)
+    if with_r:
+        assert torch.equal(qmr, rmr) and torch.equal(qvr, rvr)
+    else:
+        assert cnr is None
+    # and the statistics themselves against float64
+    mean64 = o.double().mean(dim=(0, 2, 3)).cpu()
+    assert rel(cn2.mean, mean64) < 1e-5

@@ -2,6 +2,8 @@
 golden vectors produced by the reference's own modules (tests/golden/*.npz), on the same
 closed-form inputs and weights.  float32: 1e-4; bfloat16: 2e-2 (relative to the max-abs of the
 reference tensor; for whole-model gradients in bf16, relative L2 error per tensor)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -253,7 +255,12 @@ def test_model(net, golden, ci, dtype):
         # 2. Directly against the reference's own gradients (its ReLU decisions, its logits): every 257th element of
         #    every tensor is in the fixtures.  One differing decision switches one element's gradient path on or off,
         #    which moves the small tensors of these two-clip cases (edge_importance: 73 sums) by up to 1e-2; with no
-        #    differing decision (it happens: the count varies with the order of the BatchNorm atomics) the match is 1e-4.
+        #    differing decision (it happens: the count varies with the last bits of the BatchNorm coefficients) what is left
+        #    is the float32 forward: logits off by 1e-6 put a relative error of about 1e-5 into d loss / d logits, and the
+        #    backward of these two-clip cases cancels 13-68x, so single tensors sit up to 1e-3 from the reference's
+        #    (kin_small_train_oddT: 1.0e-3 on BN1's beta of block 0 with no decision differing, while check 3 below,
+        #    which hands the GPU's own d loss / d logits to the oracle, agrees to 4e-6).  The case with a margin on every
+        #    ReLU input is the one held to 1e-4 directly.
         dd = sorted(((rel_l2(_sample(got[k]), G[name + "/gsample:" + k]), k) for k in got), reverse=True)
         direct = dd[0][0]
         print("worst gradient rel-L2 deviations from the reference's golden samples:", dd[:4])
@@ -262,7 +269,7 @@ def test_model(net, golden, ci, dtype):
         #    ill-conditioned cases (each gradient is what is left of sums that cancel 10-70x) they sit 30-60 % from the
         #    float64 ones.  tests/test_oracle_golden.py::test_one_relu_decision_moves_gradients shows the same
         #    sensitivity inside float64 alone.  bf16 is therefore bounded against the decision-consistent oracle below.
-        assert direct < (1e-4 + 1.5e-2 * nflip if dtype == torch.float32 else 1.0), (direct, nflip)
+        assert direct < (2e-3 + 1.5e-2 * nflip if dtype == torch.float32 else 1.0), (direct, nflip)
         if "margin" in name and dtype == torch.float32:
             # every ReLU input of this case is at least 1.8e-5 rms away from zero in float64 (the fixture holds the
             # margin), so float32 takes the reference's decisions and its gradients match the reference's own, with no
@@ -627,10 +634,19 @@ def test_large_batch_bf16_inference_sweep(net, lay, strat, ncls):
     probes = (0, N // 2 - 2, N - 2)
     with torch.no_grad():
         big = m(x)
-        pairs = torch.cat([m(x[i:i + 2]) for i in probes])
+        pairs_default = torch.cat([m(x[i:i + 2]) for i in probes])
+        # a two-clip batch does not fill the chip, so by default its 128 / 256-channel convolutions take another kernel
+        # than the large batch's (smaller tiles, another order of additions); with the grid condition lifted both run
+        # the same kernels
+        os.environ["STGCN_CONV_WIDE_ANY_GRID"] = "1"
+        try:
+            pairs = torch.cat([m(x[i:i + 2]) for i in probes])
+        finally:
+            del os.environ["STGCN_CONV_WIDE_ANY_GRID"]
     assert torch.isfinite(big).all()
     ref = torch.cat([big[i:i + 2] for i in probes])
     assert float((ref - pairs).abs().max() / pairs.abs().max()) < 1e-6      # same kernels, same rows: same bits up to tile order
+    assert float((ref - pairs_default).abs().max() / pairs.abs().max()) < 1e-3      # other kernels: bf16 roundings fall differently
     # and against the float64 oracle for one clip pair (bf16 tolerance)
     lo, _, _ = O.model_forward({k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}, x[:2].cpu().double(), False)
     assert rel(cpu64(big[:2]), lo) < TOL[torch.bfloat16]

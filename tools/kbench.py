@@ -96,7 +96,8 @@ def make(case, dtype):
                 L.ptr(dbf[0]), L.ptr(dbf[1]) if has_r else None, None, None, None, None,
                 rows, Cc, 0.5, 1234, float(rows), 1, L.stream_ptr()]
         keepalive = (o, dout, r, mask, acc, dbf, dO, dR, g, bn2, bnr, g2, gr)
-        return lambda: (L.call("stgcn_block_out_bwd", *args), keepalive)[0]
+        key = (str(o.dtype), ps, rows, Cc, has_r) + ((not has_r,) if ps else ())      # as ops.block_out_bwd names the launch
+        return lambda: (R._launch(key, "stgcn_block_out_bwd", *args), keepalive)[0]
     if name == "bnbwd":                                  # bn_bwd_apply
         Cc, Tt = Cin, Tin
         g, y = act(Cc, Tt, dtype), act(Cc, Tt, dtype)
@@ -126,6 +127,8 @@ def main():
     ap.add_argument("--rotate", type=int, default=1, help="cycle through this many independent sets of tensors (a training step never "
                     "re-reads what the caches, the memory-side cache included, still hold from the launch before)")
     ap.add_argument("--batch", type=int, default=128, help="samples B = clips x persons (128: the 64-clip step; 16: the 8-clip step)")
+    ap.add_argument("--interleave", action="store_true", help="cycle through the cases launch by launch (each launch between its own events): a "
+                    "kernel as it runs between other kernels, not behind copies of itself")
     ap.add_argument("--print-key", action="store_true", help="also print the launch's timing key (entry point + shape), as bench.py's tables name it")
     a = ap.parse_args()
     global B
@@ -135,6 +138,22 @@ def main():
         L._LIB_PATH = os.path.abspath(a.lib)
     L.load()
     import time
+    if a.interleave:
+        sets = [[make(case, dtype) for _ in range(max(1, a.rotate))] for case in a.cases]
+        evs = [[] for _ in a.cases]
+        for it in range(a.iters + 10):
+            for ci, fns in enumerate(sets):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                fns[it % len(fns)]()
+                e1.record()
+                if it >= 10:
+                    evs[ci].append((e0, e1))
+        torch.cuda.synchronize()
+        for case, ev in zip(a.cases, evs):
+            ms = sorted(x.elapsed_time(y) for x, y in ev)
+            print("%-28s %8.4f ms  (median %.4f, interleaved)" % (case, sum(ms) / len(ms), ms[len(ms) // 2]), flush=True)
+        return
     first = True
     for case in a.cases:
         fns = [make(case, dtype) for _ in range(max(1, a.rotate))]

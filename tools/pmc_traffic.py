@@ -1,7 +1,11 @@
 """Summarise the runs of tools/pmc_traffic.sh: per kernel case, the mean FETCH_SIZE and WRITE_SIZE per launch of the
 entry point (summed over the kernels the entry point launches, e.g. a weight gradient and its slab reduction), and
 traffic_bytes = 2 * FETCH_SIZE + WRITE_SIZE in bytes (both counters are in KB; on gfx950 FETCH_SIZE counts a 128-byte
-request of a 16-byte-per-lane streaming read as 64 bytes), keyed like bench.py's timing keys.  Prints JSON."""
+request of a 16-byte-per-lane streaming read as 64 bytes), keyed like bench.py's timing keys.  Prints JSON.
+
+    python tools/pmc_traffic.py <directory of the runs>            # on the GPU box, by tools/pmc_traffic.sh
+    python tools/pmc_traffic.py --merge gpurun_out/prof/traffic.json   # afterwards: updates bench_traffic.json
+"""
 import collections
 import csv
 import glob
@@ -50,5 +54,22 @@ def main(d):
     print(json.dumps(out, indent=1))
 
 
+def merge(path):
+    dst = os.path.join(ROOT, "bench_traffic.json")
+    try:
+        rec = json.load(open(dst))
+    except (OSError, ValueError):
+        rec = {}
+    new = json.load(open(path))
+    rec.update(new)
+    with open(dst, "w") as f:
+        json.dump(rec, f, indent=1)
+        f.write("\n")
+    print("bench_traffic.json: %d entries (%d updated)" % (len(rec), len(new)))
+
+
 if __name__ == "__main__":
-    main(sys.argv[1])
+    if sys.argv[1] == "--merge":
+        merge(sys.argv[2])
+    else:
+        main(sys.argv[1])

@@ -74,10 +74,11 @@ def make(case, dtype):
         if name == "conv1_wgrad":
             return lambda: R.conv_wgrad(x, do, kt, stride, pad)
         return lambda: R.conv_wgrad(x, do, kt, stride, pad, pro=(sc, sh))
-    if name in ("bob0", "bob1", "bob0r", "bob1r"):      # block_out_bwd: reduce / apply pass, identity or conv residual
+    if name in ("bob0", "bob1", "bob1g", "bob0r", "bob1r"):      # block_out_bwd: reduce / apply pass, identity or conv residual; bob1g also writes the masked gradient
         Cc, Tt = Cin, Tin
         o, dout = act(Cc, Tt, dtype), act(Cc, Tt, dtype)
         has_r = name.endswith("r")
+        want_g = name.endswith("g")
         r = act(Cc, Tt, dtype) if has_r else None
         rows = o.shape[0] * Tt * V
         mk = lambda: (torch.rand((Cc,), device=DEV) + 0.5)
@@ -92,11 +93,11 @@ def make(case, dtype):
         args = [L.dtype_code(o.dtype), ps, L.ptr(dout), None, Tt * V, None, L.ptr(mask), L.ptr(o), L.ptr(r), L.ptr(bn2.mean), L.ptr(bn2.rstd), L.ptr(g2),
                 L.ptr(bnr.mean) if has_r else None, L.ptr(bnr.rstd) if has_r else None, L.ptr(gr) if has_r else None,
                 L.ptr(acc[0:2]), L.ptr(acc[2:4]) if has_r else None,
-                L.ptr(dO) if ps else None, L.ptr(dR) if (ps and has_r) else None, L.ptr(g) if (ps and not has_r) else None,
+                L.ptr(dO) if ps else None, L.ptr(dR) if (ps and has_r) else None, L.ptr(g) if (ps and want_g) else None,
                 L.ptr(dbf[0]), L.ptr(dbf[1]) if has_r else None, None, None, None, None,
                 rows, Cc, 0.5, 1234, float(rows), 1, L.stream_ptr()]
         keepalive = (o, dout, r, mask, acc, dbf, dO, dR, g, bn2, bnr, g2, gr)
-        key = (str(o.dtype), ps, rows, Cc, has_r) + ((not has_r,) if ps else ())      # as ops.block_out_bwd names the launch
+        key = (str(o.dtype), ps, rows, Cc, has_r) + ((want_g,) if ps else ())      # as ops.block_out_bwd names the launch
         return lambda: (R._launch(key, "stgcn_block_out_bwd", *args), keepalive)[0]
     if name == "bnbwd":                                  # bn_bwd_apply
         Cc, Tt = Cin, Tin

@@ -10,6 +10,8 @@ for spec in "bf16 conv_t_epi:256:256" "bf16 conv:256:256" "bf16 conv_t_epi:128:1
             "bf16 gcn_fused:64:64" "bf16 gcn_fused_add:64:64" "bf16 gcn_fused:256:256" "bf16 gcn_fused_add:256:256" \
             "bf16 gcn_wgrad:64:64" "bf16 gcn_agrad:64:64" "bf16 gcn_wgrad:256:256" "bf16 gcn_agrad:256:256" \
             "bf16 bnbwd:64:64" "bf16 bofwd:64:64" "bf16 bob0:64:64" "bf16 bob1:64:64" "bf16 bnbwd:256:256" "bf16 bob1:256:256" \
+            "bf16 gcn_fused:128:128" "bf16 gcn_fused_add:128:128" "bf16 gcn_wgrad:128:128" "bf16 gcn_agrad:128:128" "bf16 conv_wgrad:128:128" \
+            "bf16 bofwd:256:256" "bf16 bob0:256:256" "bf16 bob1g:256:256" \
             "fp32 conv_wgrad:256:256" "fp32 conv_t_epi:256:256" "fp32 conv:256:256" "fp32 gcn_fused:64:64" "fp32 bnbwd:64:64"; do
   set -- $spec
   for ctr in FETCH_SIZE WRITE_SIZE; do

@@ -50,13 +50,16 @@ def main():
         B = rng.choice([1, 2, 3, 5])
         Cin = rng.choice([64, 128, 256])
         Cout = rng.choice([64, 128, 192, 256, 320, 72])
-        kt = rng.choice([1, 1, 9, 9, 3, 5])
+        kt = rng.choice([1, 1, 9, 9, 3, 5, 7, 4, 6])
         stride = rng.choice([1, 2, 2])
         V = rng.choice([1, 7, 18, 25, 25, 32])
         T = rng.choice([1, 2, 3, 9, 20, 37, 64, 150])
         pad = (kt - 1) // 2
         pro = kt > 1 and rng.random() < 0.5
         case = (B, Cin, Cout, T, V, kt, stride, pad, pro)
+        if (T + 2 * pad - kt) // stride + 1 < 1:            # an even tap count on a clip shorter than the kernel: no output frame
+            continue
+        print(i, case, end=" ", flush=True)
         x = q(t64((B, Cin, T, V), 100 + i))
         W = q(t64((Cout, Cin, kt), 200 + i) * (1.5 / np.sqrt(Cin * kt)))
         b = t64((Cout,), 300 + i, -0.2, 0.2)
@@ -82,7 +85,7 @@ def main():
         worst = max(errs.values())
         flag = "" if worst < TOL and all(np.isfinite(v) for v in errs.values()) else "   <-- FAIL"
         bad += bool(flag)
-        print(i, case, " ".join("%s %.1e" % kv for kv in errs.items()) + flag, flush=True)
+        print(" ".join("%s %.1e" % kv for kv in errs.items()) + flag, flush=True)
     print("FUZZ_DONE failures", bad)
     sys.exit(1 if bad else 0)
 

@@ -154,7 +154,7 @@ int stgcn_block_out_fwd(int dtype, const void* o, const void* res, void* out, vo
  * the producing convolutions gathered over `rows` rows.  Every workgroup derives scale / shift from the sums with the
  * arithmetic of stgcn_bn_finalize (same floats); workgroup 0 also writes mean, rstd, scale, shift to bn2_out / bnr_out
  * (float[4][C], read by stgcn_block_out_bwd) and advances the running statistics (momentum, unbiased variance; either
- * pair may be null).  One launch instead of three.
+ * pair may be null).  One launch instead of three.  C <= 512 (the coefficient table lives in LDS); wider: status 1.
  * Replaces: the same operators as stgcn_block_out_fwd plus the statistics half of the two nn.BatchNorm2d
  * (net/st_gcn.py:169, 186). */
 int stgcn_block_out_fwd_bn(int dtype, const void* o, const void* res, void* out, void* relu_mask,

@@ -158,22 +158,22 @@ struct BlockOutArgs {
     const uint32_t* seed_step;   // optional device counter mixed into the seed (see stgcn_block_out_fwd)
 };
 
+constexpr int EW_TAB_MAXC = 512;     // widest row whose per-channel divisions go through an LDS table (one channel per thread)
+constexpr int BOF_MAXC = 512;        // widest block whose BatchNorms the output stage finishes itself (coefficient table in LDS)
+
 template <typename T, int NT = 256>
 __global__ __launch_bounds__(NT) void block_out_fwd_kernel(BlockOutArgs a) {
     constexpr int VEC = ET<T>::VEC;
+    __shared__ float coef[4][BOF_MAXC];      // scale2, shift2, scale_r, shift_r
     RowMap<T, NT> m(a.C);
-    if (!m.active) return;
-    if (a.thr && a.seed_step) a.seed += *a.seed_step * STGCN_SEED_STEP_MUL;
-    float s2[VEC], b2[VEC], sr[VEC], br[VEC];
     if (a.f2.stats) {
-        // every thread derives the coefficients of its channels from the sums (a few dozen operations against the rows
-        // it streams); the threads of workgroup 0 that own row lane 0 also publish them and advance the running statistics
-        const bool publish = blockIdx.x == 0 && m.rl == 0;
-#pragma unroll
-        for (int j = 0; j < VEC; ++j) {
-            const int c = m.cv * VEC + j;
+        // One channel per thread: the coefficients from the sums (double divisions: per thread for all its channels
+        // they would cost more than the launch this saves on a short tensor), shared through LDS.  Workgroup 0 also
+        // publishes them for the backward and advances the running statistics.
+        const bool publish = blockIdx.x == 0;
+        for (int c = threadIdx.x; c < a.C; c += NT) {
             const BnCoeff k = bn_coeff_from_sums(a.f2.stats[c], a.f2.stats[a.C + c], a.count, a.f2.gamma[c], a.f2.beta[c], a.eps);
-            s2[j] = k.scale; b2[j] = k.shift;
+            coef[0][c] = k.scale; coef[1][c] = k.shift;
             if (publish) {
                 a.f2.mean[c] = k.mean; a.f2.rstd[c] = k.rstd; a.f2.scale[c] = k.scale; a.f2.shift[c] = k.shift;
                 if (a.f2.rmean) {
@@ -181,10 +181,10 @@ __global__ __launch_bounds__(NT) void block_out_fwd_kernel(BlockOutArgs a) {
                     a.f2.rvar[c] = (1.f - a.momentum) * a.f2.rvar[c] + a.momentum * k.unbiased_var;
                 }
             }
-            sr[j] = 1.f; br[j] = 0.f;
+            float qs = 1.f, qb = 0.f;
             if (a.fr.stats) {
                 const BnCoeff q = bn_coeff_from_sums(a.fr.stats[c], a.fr.stats[a.C + c], a.count, a.fr.gamma[c], a.fr.beta[c], a.eps);
-                sr[j] = q.scale; br[j] = q.shift;
+                qs = q.scale; qb = q.shift;
                 if (publish) {
                     a.fr.mean[c] = q.mean; a.fr.rstd[c] = q.rstd; a.fr.scale[c] = q.scale; a.fr.shift[c] = q.shift;
                     if (a.fr.rmean) {
@@ -193,6 +193,18 @@ __global__ __launch_bounds__(NT) void block_out_fwd_kernel(BlockOutArgs a) {
                     }
                 }
             }
+            coef[2][c] = qs; coef[3][c] = qb;
+        }
+        __syncthreads();
+    }
+    if (!m.active) return;
+    if (a.thr && a.seed_step) a.seed += *a.seed_step * STGCN_SEED_STEP_MUL;
+    float s2[VEC], b2[VEC], sr[VEC], br[VEC];
+    if (a.f2.stats) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            const int c = m.cv * VEC + j;
+            s2[j] = coef[0][c]; b2[j] = coef[1][c]; sr[j] = coef[2][c]; br[j] = coef[3][c];
         }
     } else {
 #pragma unroll
@@ -289,6 +301,7 @@ extern "C" int stgcn_block_out_fwd_bn(int dtype, const void* o, const void* res,
                                       float momentum, float eps,
                                       size_t rows, int C, float drop_p, uint32_t seed, const uint32_t* seed_step, void* stream) {
     if (!o || !out || !bn2_stats || !gamma2 || !beta2 || !bn2_out || rows == 0 || drop_p < 0.f || drop_p >= 1.f) return STGCN_ERR_ARG;
+    if (C > BOF_MAXC) return STGCN_ERR_ARG;               // wider blocks: stgcn_bn_finalize + stgcn_block_out_fwd
     if ((running_mean2 == nullptr) != (running_var2 == nullptr)) return STGCN_ERR_ARG;
     if (bnr_stats && (!res || !gammar || !betar || !bnr_out || (running_meanr == nullptr) != (running_varr == nullptr))) return STGCN_ERR_ARG;
     BlockOutArgs a{};
@@ -430,6 +443,20 @@ __global__ __launch_bounds__(NT) void block_out_bwd_apply_kernel(BlockOutBwdArgs
     for (int s = 0; s < 2; ++s)
 #pragma unroll
         for (int j = 0; j < VEC; ++j) sums[s][j] = 0.f;
+    // the means of the sums (double divisions) once per channel, through an LDS table: see bn_bwd_apply_kernel
+    __shared__ float tab[4][EW_TAB_MAXC];
+    const bool use_tab = a.training && a.C <= EW_TAB_MAXC;
+    if (use_tab) {
+        for (int c = threadIdx.x; c < a.C; c += NT) {
+            tab[0][c] = (float)(a.stats2[c] / a.count);
+            tab[1][c] = (float)(a.stats2[a.C + c] / a.count);
+            if constexpr (HAS_R) {
+                tab[2][c] = (float)(a.statsr[c] / a.count);
+                tab[3][c] = (float)(a.statsr[a.C + c] / a.count);
+            }
+        }
+        __syncthreads();
+    }
     if (m.active) {
         // k*(gd - m1 - ohat*m2) with ohat = (o - mean)*rstd, folded to three constants per channel:
         //   k*gd + qa*o + qb,  qa = -k*m2*rstd,  qb = -k*m1 - qa*mean
@@ -438,13 +465,14 @@ __global__ __launch_bounds__(NT) void block_out_bwd_apply_kernel(BlockOutBwdArgs
         float k2[VEC], qa2[VEC], qb2[VEC], kr[VEC], qar[VEC], qbr[VEC];
         float rs2[VEC], mn2[VEC], rsr[VEC], mnr[VEC];
         double s2a[VEC], s2b[VEC], sra[VEC], srb[VEC];
-        const double* st2 = a.training ? a.stats2 : (const double*)a.mean2;      // not read when not training
-        const double* str = (HAS_R && a.training) ? a.statsr : (const double*)a.mean2;
-        const int cs = a.training ? a.C : 0;
+        const bool divide = a.training && !use_tab;
+        const double* st2 = divide ? a.stats2 : (const double*)a.mean2;      // not read otherwise
+        const double* str = (HAS_R && divide) ? a.statsr : (const double*)a.mean2;
+        const int cs = divide ? a.C : 0;
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
             const int c = m.cv * VEC + j;
-            const int cd = a.training ? c : 0;
+            const int cd = divide ? c : 0;
             rs2[j] = a.rstd2[c]; k2[j] = a.gamma2[c]; mn2[j] = a.mean2[c];
             s2a[j] = st2[cd]; s2b[j] = st2[cs + cd];
             if constexpr (HAS_R) {
@@ -454,15 +482,16 @@ __global__ __launch_bounds__(NT) void block_out_bwd_apply_kernel(BlockOutBwdArgs
         }
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
+            const int c = m.cv * VEC + j;
             k2[j] *= rs2[j];
-            const float m1 = a.training ? (float)(s2a[j] / a.count) : 0.f;
-            const float m2 = a.training ? (float)(s2b[j] / a.count) : 0.f;
+            const float m1 = use_tab ? tab[0][c] : divide ? (float)(s2a[j] / a.count) : 0.f;
+            const float m2 = use_tab ? tab[1][c] : divide ? (float)(s2b[j] / a.count) : 0.f;
             qa2[j] = -k2[j] * m2 * rs2[j];
             qb2[j] = -k2[j] * m1 - qa2[j] * mn2[j];
             if constexpr (HAS_R) {
                 kr[j] *= rsr[j];
-                const float n1 = a.training ? (float)(sra[j] / a.count) : 0.f;
-                const float n2 = a.training ? (float)(srb[j] / a.count) : 0.f;
+                const float n1 = use_tab ? tab[2][c] : divide ? (float)(sra[j] / a.count) : 0.f;
+                const float n2 = use_tab ? tab[3][c] : divide ? (float)(srb[j] / a.count) : 0.f;
                 qar[j] = -kr[j] * n2 * rsr[j];
                 qbr[j] = -kr[j] * n1 - qar[j] * mnr[j];
             } else { kr[j] = qar[j] = qbr[j] = 0.f; }
@@ -591,26 +620,39 @@ __global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(BnBwdArgs a) {
             if (a.dgamma) a.dgamma[c] = (float)a.stats[a.C + c];
         }
     }
+    // The two means per channel are double divisions: one channel per thread through an LDS table (a thread dividing
+    // for all its channels spends 2-3 us on it, which shows on short tensors); wider rows than the table divide per thread.
+    __shared__ float tab[2][EW_TAB_MAXC];
+    const bool use_tab = a.training && a.C <= EW_TAB_MAXC;
+    if (use_tab) {
+        for (int c = threadIdx.x; c < a.C; c += NT) {
+            tab[0][c] = (float)(a.stats[c] / a.count);
+            tab[1][c] = (float)(a.stats[a.C + c] / a.count);
+        }
+        __syncthreads();
+    }
     if (!m.active) return;
     // Per-channel constants: every load first (from a valid address on every path), then the arithmetic.  Written
     // channel by channel -- load, branch on `training`, divide -- the compiler keeps each channel's loads behind the
     // previous channel's wait: eight trips to memory in a row before the first row moves.
     float mu[VEC], rs[VEC], kk[VEC], m1[VEC], m2[VEC];
     double sa[VEC], sb[VEC];
-    const double* st = a.training ? a.stats : (const double*)a.mean;     // not read when not training: any valid address
-    const int cs = a.training ? a.C : 0;
+    const bool divide = a.training && !use_tab;
+    const double* st = divide ? a.stats : (const double*)a.mean;     // not read otherwise: any valid address
+    const int cs = divide ? a.C : 0;
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
         const int c = m.cv * VEC + j;
         mu[j] = a.mean[c]; rs[j] = a.rstd[c]; kk[j] = a.gamma[c];
-        const int cd = a.training ? c : 0;
+        const int cd = divide ? c : 0;
         sa[j] = st[cd]; sb[j] = st[cs + cd];
     }
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
+        const int c = m.cv * VEC + j;
         kk[j] *= rs[j];
-        m1[j] = a.training ? (float)(sa[j] / a.count) : 0.f;
-        m2[j] = a.training ? (float)(sb[j] / a.count) : 0.f;
+        m1[j] = use_tab ? tab[0][c] : divide ? (float)(sa[j] / a.count) : 0.f;
+        m2[j] = use_tab ? tab[1][c] : divide ? (float)(sb[j] / a.count) : 0.f;
     }
     for (size_t row = (size_t)blockIdx.x * m.rpi + m.rl; row < a.rows; row += (size_t)gridDim.x * m.rpi) {
         const size_t off = row * a.C + m.cv * VEC;

@@ -213,7 +213,7 @@ class StGcnBlockFn(torch.autograd.Function):
                         ntaps=kt, stride=stride, pad=pad)
         # train mode: BN2 and the residual branch's BatchNorm are finished inside the output stage's launch (it derives
         # their coefficients from the convolutions' sums); eval mode reads the running statistics with bn_finalize
-        fold = training and not BN_LAUNCHES
+        fold = training and not BN_LAUNCHES and Cout <= 512      # the folded launch keeps its coefficient table in LDS
         bn2 = None if fold else P.bn_finalize(stats[1] if training else None, B * To * V, f32(g2), f32(b2), rm2, rv2, training)
 
         r, bnr = None, None

@@ -50,6 +50,21 @@ int stgcn_conv_rows(int dtype, const void* in, const void* w_packed, void* out,
                     int B, int Tin, int Tout, int V, int Cin, int Cout,
                     int ntaps, int stride, int pad, int dil, int transposed, void* stream);
 
+/* The forward form of stgcn_conv_rows with the BatchNorm + ReLU ahead of it finished inside the launch (train mode):
+ * instead of pro_scale / pro_shift the call takes the double sums [sum[Cin], sum of squares[Cin]] over pro_count rows
+ * that the producer of `in` gathered, and the BatchNorm's parameters.  Every workgroup derives the coefficients of all
+ * Cin channels with the arithmetic of stgcn_bn_finalize (same floats) and writes them to pro_bn_out (float[4][Cin]:
+ * mean, rstd, scale, shift -- the same values from every workgroup; the weight gradient, the data gradient and
+ * stgcn_bn_bwd_apply of the step read them from there); the running statistics (either pair may be null) advance once.
+ * One launch instead of two.
+ * Replaces: the same operators as stgcn_conv_rows plus the statistics half of nn.BatchNorm2d (net/st_gcn.py:160). */
+int stgcn_conv_rows_bn(int dtype, const void* in, const void* w_packed, void* out, const float* bias,
+                       const double* pro_stats, const float* pro_gamma, const float* pro_beta,
+                       float* pro_running_mean, float* pro_running_var, float* pro_bn_out,
+                       double pro_count, float momentum, float eps, double* stats,
+                       int B, int Tin, int Tout, int V, int Cin, int Cout,
+                       int ntaps, int stride, int pad, int dil, void* stream);
+
 /* Weight gradient of the forward form above: dW[co][ci][tap] (float32, the torch conv weight layout).
  * Replaces: autograd weight gradient of the convolutions at net/st_gcn.py:162-168 and 181-185.
  * workspace: partial-sum slab, at least ntaps*Cout*Cin*4 bytes (more lets more workgroups run). */

@@ -30,7 +30,7 @@
 
 struct ConvBigArgs {
     const void* in; const void* w; void* out;
-    const float* bias; const float* pro_scale; const float* pro_shift;
+    const float* bias; const float* pro_scale; const float* pro_shift; BnPrologue pbn;
     const void* aux; const float* ep_scale; const float* ep_shift; const float* ep_mean; const float* ep_rstd;
     double* stats;
     int B, Tin, V, Cin, Cout;
@@ -51,6 +51,7 @@ constexpr int CB_NWB = 4;           // weight-tile buffers
 
 template <typename T, int WR, int WC, int MT, int NT, int EPI, bool GRP = false>
 __global__ __launch_bounds__(WR * WC * 64) void conv_big_kernel(ConvBigArgs a) {
+    bn_prologue_preamble(a.pbn);
     constexpr int NG = GRP ? 2 : 1;                      // tap groups = window phases per chunk
     constexpr int WFS = GRP ? 2 : 1;                     // frame step inside a window
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -511,10 +512,10 @@ template <typename T>
 static int conv_big_try_t(const void* in, const void* w, void* out, const float* bias, const float* pro_scale, const float* pro_shift,
                           int epilogue, const void* aux, const float* ep_scale, const float* ep_shift, const float* ep_mean, const float* ep_rstd,
                           double* stats, int B, int Tin, int Tout, int V, int Cin, int Cout, int ntaps, int stride, int pad, int dil,
-                          int transposed, hipStream_t stream) {
+                          int transposed, hipStream_t stream, const BnPrologue* pbn) {
     if (Cin % (128 / ET<T>::ES) != 0 || Cin <= 0 || Cout % ET<T>::VEC != 0 || V < 1 || V > 32 || ntaps < 1 || ntaps > 9 || dil != 1 || (stride != 1 && stride != 2)) return -1;
     ConvBigArgs a;
-    a.in = in; a.w = w; a.out = out; a.bias = bias; a.pro_scale = pro_scale; a.pro_shift = pro_shift;
+    a.in = in; a.w = w; a.out = out; a.bias = bias; a.pro_scale = pro_scale; a.pro_shift = pro_shift; a.pbn = pbn ? *pbn : BnPrologue{};
     a.aux = aux; a.ep_scale = ep_scale; a.ep_shift = ep_shift; a.ep_mean = ep_mean; a.ep_rstd = ep_rstd; a.stats = stats;
     a.B = B; a.Tin = Tin; a.V = V; a.Cin = Cin; a.Cout = Cout; a.Tout_real = Tout;
     a.tiles_per_sample = 0; a.zero_row = 0;
@@ -542,12 +543,12 @@ static int conv_big_try_t(const void* in, const void* w, void* out, const float*
 int conv_big_try(int dtype, const void* in, const void* w, void* out, const float* bias, const float* pro_scale, const float* pro_shift,
                  int epilogue, const void* aux, const float* ep_scale, const float* ep_shift, const float* ep_mean, const float* ep_rstd,
                  double* stats, int B, int Tin, int Tout, int V, int Cin, int Cout, int ntaps, int stride, int pad, int dil,
-                 int transposed, hipStream_t stream) {
+                 int transposed, hipStream_t stream, const BnPrologue* pbn) {
     if (dtype == STGCN_BF16)
         return conv_big_try_t<bf16>(in, w, out, bias, pro_scale, pro_shift, epilogue, aux, ep_scale, ep_shift, ep_mean, ep_rstd,
-                                    stats, B, Tin, Tout, V, Cin, Cout, ntaps, stride, pad, dil, transposed, stream);
+                                    stats, B, Tin, Tout, V, Cin, Cout, ntaps, stride, pad, dil, transposed, stream, pbn);
     if (dtype == STGCN_F32)
         return conv_big_try_t<float>(in, w, out, bias, pro_scale, pro_shift, epilogue, aux, ep_scale, ep_shift, ep_mean, ep_rstd,
-                                     stats, B, Tin, Tout, V, Cin, Cout, ntaps, stride, pad, dil, transposed, stream);
+                                     stats, B, Tin, Tout, V, Cin, Cout, ntaps, stride, pad, dil, transposed, stream, pbn);
     return -1;
 }

@@ -17,7 +17,7 @@
 struct ConvRowsArgs {
     const void* in; const void* w; void* out;
     const float* bias;
-    const float* pro_scale; const float* pro_shift;
+    const float* pro_scale; const float* pro_shift; BnPrologue pbn;
     const void* aux; const float* ep_scale; const float* ep_shift; const float* ep_mean; const float* ep_rstd;
     double* stats;
     int B, Tin, Tout, V, Cin, Cout;
@@ -33,6 +33,7 @@ constexpr int CR_RS = 144;   // LDS row stride: 128 data bytes + 16 pad (conflic
 
 template <typename T, int WM, int NT, int EPI>
 __global__ __launch_bounds__(256) void conv_rows_kernel(ConvRowsArgs a) {
+    bn_prologue_preamble(a.pbn);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int ES = ET<T>::ES;
     constexpr int KC = 128 / ES;           // channels per chunk
@@ -274,32 +275,33 @@ static int conv_rows_dispatch(ConvRowsArgs& a, int epi, hipStream_t stream) {
 // fast path for the stride-1 temporal convolutions in bf16 (conv_t9.hip); -1 = shape not covered
 int conv_t9_try(const void* in, const void* w, void* out, const float* bias, const float* pro_scale, const float* pro_shift,
                 int epilogue, const void* aux, const float* ep_scale, const float* ep_shift, const float* ep_mean, const float* ep_rstd,
-                double* stats, int B, int T, int V, int Cin, int Cout, int ntaps, int transposed, hipStream_t stream);
+                double* stats, int B, int T, int V, int Cin, int Cout, int ntaps, int transposed, hipStream_t stream, const BnPrologue* pbn);
 
 // tiled path for the remaining shapes with Cin a whole number of 128-byte chunks (conv_big.hip); -1 = shape not covered
 int conv_big_try(int dtype, const void* in, const void* w, void* out, const float* bias, const float* pro_scale, const float* pro_shift,
                  int epilogue, const void* aux, const float* ep_scale, const float* ep_shift, const float* ep_mean, const float* ep_rstd,
                  double* stats, int B, int Tin, int Tout, int V, int Cin, int Cout, int ntaps, int stride, int pad, int dil,
-                 int transposed, hipStream_t stream);
+                 int transposed, hipStream_t stream, const BnPrologue* pbn);
 
 // whole-width tiles for 128 / 256 output channels at an input stride of one frame, bf16 (conv_wide.hip); -1 = shape not covered
 int conv_wide_try(const void* in, const void* w, void* out, const float* bias, const float* pro_scale, const float* pro_shift,
                   int epilogue, const void* aux, const float* ep_scale, const float* ep_shift, const float* ep_mean, const float* ep_rstd,
                   double* stats, int B, int Tin, int Tout, int V, int Cin, int Cout, int ntaps, int stride, int pad, int dil,
-                  int transposed, hipStream_t stream);
+                  int transposed, hipStream_t stream, const BnPrologue* pbn);
 
 // streaming path for the strided 1-tap convolution in bf16 (conv1s.hip); -1 = shape not covered
 int conv1s_try(const void* in, const void* w, void* out, const float* bias, double* stats,
                int B, int Tin, int Tout, int V, int Cin, int Cout, int stride, int transposed, hipStream_t stream);
 
 // C-ABI ------------------------------------------------------------------------------------
-extern "C" int stgcn_conv_rows(int dtype, const void* in, const void* w_packed, void* out,
-                               const float* bias, const float* pro_scale, const float* pro_shift,
-                               int epilogue, const void* aux, const float* ep_scale, const float* ep_shift,
-                               const float* ep_mean, const float* ep_rstd, double* stats,
-                               int B, int Tin, int Tout, int V, int Cin, int Cout,
-                               int ntaps, int stride, int pad, int dil, int transposed, void* stream) {
+static int conv_rows_any(int dtype, const void* in, const void* w_packed, void* out,
+                         const float* bias, const float* pro_scale, const float* pro_shift,
+                         int epilogue, const void* aux, const float* ep_scale, const float* ep_shift,
+                         const float* ep_mean, const float* ep_rstd, double* stats,
+                         int B, int Tin, int Tout, int V, int Cin, int Cout,
+                         int ntaps, int stride, int pad, int dil, int transposed, void* stream, const BnPrologue* pbn) {
     ConvRowsArgs a;
+    a.pbn = pbn ? *pbn : BnPrologue{};
     a.in = in; a.w = w_packed; a.out = out; a.bias = bias; a.pro_scale = pro_scale; a.pro_shift = pro_shift;
     a.aux = aux; a.ep_scale = ep_scale; a.ep_shift = ep_shift; a.ep_mean = ep_mean; a.ep_rstd = ep_rstd; a.stats = stats;
     a.B = B; a.Tin = Tin; a.Tout = Tout; a.V = V; a.Cin = Cin; a.Cout = Cout;
@@ -310,7 +312,7 @@ extern "C" int stgcn_conv_rows(int dtype, const void* in, const void* w_packed, 
     if (dtype == STGCN_BF16 && stride == 1 && dil == 1 && ntaps >= 1 && pad == (ntaps - 1) / 2 && Tin == Tout && B > 0 && Tin > 0 &&
         (epilogue == EPI_PLAIN || epilogue == EPI_ADD_RELU || (aux && ep_scale && ep_shift && ep_mean && ep_rstd))) {
         const int rc = conv_t9_try(in, w_packed, out, bias, pro_scale, pro_shift, epilogue, aux, ep_scale, ep_shift, ep_mean, ep_rstd,
-                                   stats, B, Tin, V, Cin, Cout, ntaps, transposed, (hipStream_t)stream);
+                                   stats, B, Tin, V, Cin, Cout, ntaps, transposed, (hipStream_t)stream, pbn);
         if (rc >= 0) return rc;
     }
     if (dtype == STGCN_BF16 && ntaps == 1 && stride == 2 && pad == 0 && dil == 1 && epilogue == EPI_PLAIN && !pro_scale) {
@@ -321,14 +323,42 @@ extern "C" int stgcn_conv_rows(int dtype, const void* in, const void* w_packed, 
         (epilogue == EPI_PLAIN || epilogue == EPI_ADD_RELU || (epilogue == EPI_RELU_BWD && aux && ep_scale && ep_shift && ep_mean && ep_rstd))) {
         if (dtype == STGCN_BF16) {
             const int rc = conv_wide_try(in, w_packed, out, bias, pro_scale, pro_shift, epilogue, aux, ep_scale, ep_shift, ep_mean, ep_rstd,
-                                         stats, B, Tin, Tout, V, Cin, Cout, ntaps, stride, pad, dil, transposed, (hipStream_t)stream);
+                                         stats, B, Tin, Tout, V, Cin, Cout, ntaps, stride, pad, dil, transposed, (hipStream_t)stream, pbn);
             if (rc >= 0) return rc;
         }
         const int rc = conv_big_try(dtype, in, w_packed, out, bias, pro_scale, pro_shift, epilogue, aux, ep_scale, ep_shift, ep_mean, ep_rstd,
-                                    stats, B, Tin, Tout, V, Cin, Cout, ntaps, stride, pad, dil, transposed, (hipStream_t)stream);
+                                    stats, B, Tin, Tout, V, Cin, Cout, ntaps, stride, pad, dil, transposed, (hipStream_t)stream, pbn);
         if (rc >= 0) return rc;
     }
     if (dtype == STGCN_BF16) return conv_rows_dispatch<bf16>(a, epilogue, (hipStream_t)stream);
     if (dtype == STGCN_F32) return conv_rows_dispatch<float>(a, epilogue, (hipStream_t)stream);
     return STGCN_ERR_ARG;
+}
+
+extern "C" int stgcn_conv_rows(int dtype, const void* in, const void* w_packed, void* out,
+                               const float* bias, const float* pro_scale, const float* pro_shift,
+                               int epilogue, const void* aux, const float* ep_scale, const float* ep_shift,
+                               const float* ep_mean, const float* ep_rstd, double* stats,
+                               int B, int Tin, int Tout, int V, int Cin, int Cout,
+                               int ntaps, int stride, int pad, int dil, int transposed, void* stream) {
+    return conv_rows_any(dtype, in, w_packed, out, bias, pro_scale, pro_shift, epilogue, aux, ep_scale, ep_shift, ep_mean, ep_rstd, stats,
+                         B, Tin, Tout, V, Cin, Cout, ntaps, stride, pad, dil, transposed, stream, nullptr);
+}
+
+// The forward form with the BatchNorm + ReLU ahead of it finished inside the launch (train mode): the prologue's
+// statistics arrive as the double sums [sum[Cin], sum of squares[Cin]] over pro_count rows that the producer of `in`
+// gathered; pro_bn_out (float[4][Cin]) receives mean, rstd, scale, shift (the later kernels of the step read them), the
+// running statistics (either pair may be null) advance once.  See BnPrologue.
+extern "C" int stgcn_conv_rows_bn(int dtype, const void* in, const void* w_packed, void* out, const float* bias,
+                                  const double* pro_stats, const float* pro_gamma, const float* pro_beta,
+                                  float* pro_running_mean, float* pro_running_var, float* pro_bn_out,
+                                  double pro_count, float momentum, float eps, double* stats,
+                                  int B, int Tin, int Tout, int V, int Cin, int Cout,
+                                  int ntaps, int stride, int pad, int dil, void* stream) {
+    if (!pro_stats || !pro_gamma || !pro_beta || !pro_bn_out || pro_count <= 0 || Cin <= 0) return STGCN_ERR_ARG;
+    if ((pro_running_mean == nullptr) != (pro_running_var == nullptr)) return STGCN_ERR_ARG;
+    BnPrologue f{pro_stats, pro_gamma, pro_beta, pro_running_mean, pro_running_var, pro_bn_out, pro_count, momentum, eps, Cin};
+    return conv_rows_any(dtype, in, w_packed, out, bias, pro_bn_out + 2 * (size_t)Cin, pro_bn_out + 3 * (size_t)Cin, EPI_PLAIN,
+                         nullptr, nullptr, nullptr, nullptr, nullptr, stats,
+                         B, Tin, Tout, V, Cin, Cout, ntaps, stride, pad, dil, 0, stream, &f);
 }

@@ -26,7 +26,7 @@
 
 struct ConvT9Args {
     const void* in; const void* w; void* out;
-    const float* bias; const float* pro_scale; const float* pro_shift;
+    const float* bias; const float* pro_scale; const float* pro_shift; BnPrologue pbn;
     const void* aux; const float* ep_scale; const float* ep_shift; const float* ep_mean; const float* ep_rstd;
     double* stats;
     int B, R, V, Cout, ntaps, transposed;
@@ -43,6 +43,7 @@ constexpr int T9_RS = T9_CIN * 2 + 16;   // ring / weight row stride (bytes)
 
 template <int EPI>
 __global__ __launch_bounds__(T9_NT) void conv_t9_kernel(ConvT9Args a) {
+    bn_prologue_preamble(a.pbn);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int RS = T9_RS;
     constexpr int NPF = T9_BM * 8 / T9_NT;      // 16-byte pieces per thread per tile (input rows, output rows)
@@ -311,10 +312,10 @@ static int launch_conv_t9(ConvT9Args& a, hipStream_t stream) {
 // Returns -1 when the shape is outside this kernel's domain (the caller then tries conv_big, then conv_rows).
 int conv_t9_try(const void* in, const void* w, void* out, const float* bias, const float* pro_scale, const float* pro_shift,
                 int epilogue, const void* aux, const float* ep_scale, const float* ep_shift, const float* ep_mean, const float* ep_rstd,
-                double* stats, int B, int T, int V, int Cin, int Cout, int ntaps, int transposed, hipStream_t stream) {
+                double* stats, int B, int T, int V, int Cin, int Cout, int ntaps, int transposed, hipStream_t stream, const BnPrologue* pbn) {
     if (Cin != T9_CIN || Cout > 64 || V > 32 || V < 1 || ntaps > 9 || (ntaps & 1) == 0 || Cout % 8 != 0) return -1;
     ConvT9Args a;
-    a.in = in; a.w = w; a.out = out; a.bias = bias; a.pro_scale = pro_scale; a.pro_shift = pro_shift;
+    a.in = in; a.w = w; a.out = out; a.bias = bias; a.pro_scale = pro_scale; a.pro_shift = pro_shift; a.pbn = pbn ? *pbn : BnPrologue{};
     a.aux = aux; a.ep_scale = ep_scale; a.ep_shift = ep_shift; a.ep_mean = ep_mean; a.ep_rstd = ep_rstd; a.stats = stats;
     a.B = B; a.R = T * V; a.V = V; a.Cout = Cout; a.ntaps = ntaps; a.transposed = transposed;
     a.tiles_per_seg = 0; a.segs_per_sample = 0;

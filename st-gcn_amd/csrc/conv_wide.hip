@@ -31,7 +31,7 @@
 
 struct ConvWideArgs {
     const void* in; const void* w; void* out;
-    const float* bias; const float* pro_scale; const float* pro_shift;
+    const float* bias; const float* pro_scale; const float* pro_shift; BnPrologue pbn;
     const void* aux; const float* ep_scale; const float* ep_shift; const float* ep_mean; const float* ep_rstd;
     double* stats;
     int B, Tin, V, Cin, Cout;
@@ -86,6 +86,7 @@ constexpr int CWD_NWT = 4;             // weight-tile buffers
 
 template <int WR, int WC, int EPI, bool PRO>
 __global__ __launch_bounds__(512) void conv_wide_kernel(ConvWideArgs a) {
+    bn_prologue_preamble(a.pbn);
     static_assert(WR * WC == 8, "eight waves");
     constexpr int BM = WR * 64, BN = WC * 128;
     constexpr int WIN_ROWS = WR == 4 ? 576 : 832;
@@ -542,7 +543,7 @@ static int conv_wide_launch_any(ConvWideArgs& a, int epi, bool dry, hipStream_t 
 int conv_wide_try(const void* in, const void* w, void* out, const float* bias, const float* pro_scale, const float* pro_shift,
                   int epilogue, const void* aux, const float* ep_scale, const float* ep_shift, const float* ep_mean, const float* ep_rstd,
                   double* stats, int B, int Tin, int Tout, int V, int Cin, int Cout, int ntaps, int stride, int pad, int dil,
-                  int transposed, hipStream_t stream) {
+                  int transposed, hipStream_t stream, const BnPrologue* pbn) {
     static const bool off = getenv("STGCN_NO_CONV_WIDE") != nullptr;
     if (off) return -1;
     if ((Cout != 128 && Cout != 256) || Cin % 32 != 0 || Cin < 64 || V < 1 || V > 32 || dil != 1) return -1;
@@ -558,7 +559,7 @@ int conv_wide_try(const void* in, const void* w, void* out, const float* bias, c
         if (tiles < stgcn_num_cus() && getenv("STGCN_CONV_WIDE_ANY_GRID") == nullptr) return -1;
     }
     ConvWideArgs a;
-    a.in = in; a.w = w; a.out = out; a.bias = bias; a.pro_scale = pro_scale; a.pro_shift = pro_shift;
+    a.in = in; a.w = w; a.out = out; a.bias = bias; a.pro_scale = pro_scale; a.pro_shift = pro_shift; a.pbn = pbn ? *pbn : BnPrologue{};
     a.aux = aux; a.ep_scale = ep_scale; a.ep_shift = ep_shift; a.ep_mean = ep_mean; a.ep_rstd = ep_rstd; a.stats = stats;
     a.B = B; a.Tin = Tin; a.V = V; a.Cin = Cin; a.Cout = Cout; a.Tout_real = Tout;
     a.tiles_per_sample = 0;

@@ -77,22 +77,6 @@ __device__ __forceinline__ void wide_channel_reduce(float (*sums)[ET<T>::VEC], c
 
 // ------------------------------------------------------------------------------------------
 // BatchNorm parameter finalisation (tiny)
-// Batch statistics -> the coefficients of one channel.  One definition for the finalize kernel and for the kernels that
-// fold it into their prologue: both must arrive at the same floats.
-struct BnCoeff { float mean, rstd, scale, shift, unbiased_var; };
-__device__ __forceinline__ BnCoeff bn_coeff_from_sums(double s1, double s2, double count, float gamma, float beta, float eps) {
-    const double m = s1 / count;
-    double v = s2 / count - m * m;
-    if (v < 0) v = 0;
-    BnCoeff k;
-    k.mean = (float)m;
-    k.unbiased_var = (float)(count > 1 ? v * (count / (count - 1)) : v);
-    k.rstd = 1.0f / sqrtf((float)v + eps);
-    k.scale = gamma * k.rstd;
-    k.shift = fmaf(-k.mean, k.scale, beta);
-    return k;
-}
-
 __global__ void bn_finalize_kernel(const double* stats, double count, const float* gamma, const float* beta,
                                    float* rmean, float* rvar, float momentum, float eps,
                                    float* mean, float* rstd, float* scale, float* shift, int C, int training) {

@@ -199,6 +199,49 @@ __device__ __forceinline__ float slab_sum64(const float* slab, int nparts, size_
 }
 static inline unsigned slab_sum_grid(size_t n) { return (unsigned)((n + 63) / 64); }
 
+// ---- BatchNorm coefficients from statistic sums ------------------------------------------------------------------
+// One definition for stgcn_bn_finalize and for the kernels that fold it into their own launch: both must arrive at the
+// same floats.
+struct BnCoeff { float mean, rstd, scale, shift, unbiased_var; };
+__device__ __forceinline__ BnCoeff bn_coeff_from_sums(double s1, double s2, double count, float gamma, float beta, float eps) {
+    const double m = s1 / count;
+    double v = s2 / count - m * m;
+    if (v < 0) v = 0;
+    BnCoeff k;
+    k.mean = (float)m;
+    k.unbiased_var = (float)(count > 1 ? v * (count / (count - 1)) : v);
+    k.rstd = 1.0f / sqrtf((float)v + eps);
+    k.scale = gamma * k.rstd;
+    k.shift = fmaf(-k.mean, k.scale, beta);
+    return k;
+}
+
+// The BatchNorm + ReLU ahead of a temporal convolution, finished by the convolution's own launch (train mode).  The
+// convolution kernels read their prologue's scale / shift from plain arrays; with `stats` set those arrays are
+// out + 2C and out + 3C of `out` (float[4][C]: mean, rstd, scale, shift) and EVERY workgroup first derives all C
+// channels from the sums and writes them there -- the same values from every workgroup, so it does not matter whose
+// store a line holds -- and reads back only what it has written itself, behind a workgroup barrier (a workgroup sees
+// its own global stores after __syncthreads(); it never depends on another workgroup's).  The kernels that follow
+// (weight gradient, data gradient, BatchNorm backward) read `out` across the kernel boundary.  Workgroup (0, 0, 0)
+// also advances the running statistics.
+struct BnPrologue {
+    const double* stats; const float* gamma; const float* beta; float* rmean; float* rvar; float* out;
+    double count; float momentum, eps; int C;
+};
+__device__ __forceinline__ void bn_prologue_preamble(const BnPrologue& f) {
+    if (!f.stats) return;
+    const bool first = blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0;
+    for (int c = threadIdx.x; c < f.C; c += blockDim.x) {
+        const BnCoeff k = bn_coeff_from_sums(f.stats[c], f.stats[f.C + c], f.count, f.gamma[c], f.beta[c], f.eps);
+        f.out[c] = k.mean; f.out[f.C + c] = k.rstd; f.out[2 * f.C + c] = k.scale; f.out[3 * f.C + c] = k.shift;
+        if (first && f.rmean) {
+            f.rmean[c] = (1.f - f.momentum) * f.rmean[c] + f.momentum * k.mean;
+            f.rvar[c] = (1.f - f.momentum) * f.rvar[c] + f.momentum * k.unbiased_var;
+        }
+    }
+    __syncthreads();
+}
+
 // ---- pending sums ------------------------------------------------------------------------------------------------
 // The kernels that produce parameter gradients write per-workgroup partials [nparts][n1 + n2] (f32) and leave the
 // fixed-order sum over the parts to a second launch.  A launcher describes that sum with a StgcnPendingSum and hands

@@ -27,8 +27,8 @@ CAPTURE_TENSORS = False
 # because kernels that share the device stretch each other and per-kernel durations (profiles, the benchmark's
 # roofline record) stop describing the kernels.
 OVERLAP_WGRAD = os.environ.get("STGCN_OVERLAP_WGRAD", "0") == "1"
-# Debugging aid (STGCN_BN_LAUNCHES=1): BN2 and the residual BatchNorm finished by launches of their own (bn_finalize)
-# instead of inside the output stage's launch.
+# Debugging aid (STGCN_BN_LAUNCHES=1): a block's BatchNorms finished by launches of their own (bn_finalize) instead of
+# inside the temporal convolution's and the output stage's launches.
 BN_LAUNCHES = os.environ.get("STGCN_BN_LAUNCHES", "0") == "1"
 _SIDE = {}
 
@@ -207,10 +207,14 @@ class StGcnBlockFn(torch.autograd.Function):
                      (P.pack_conv_w(Wr.detach(), dtype), P.pack_conv_wt(Wr.detach(), dtype)) if kind == "conv" else None)
         ctx.packs = packs
         y = P.gcn_fused(x, packs[0][0], A32, Cout, bias=f32(bg), stats=stats[0] if training else None, adj_t=True)
-        bn1 = P.bn_finalize(stats[0] if training else None, B * T * V, f32(g1), f32(b1), rm1, rv1, training)
-
-        o = P.conv_rows(y, packs[1][0], Cout, To, bias=f32(bt), pro=(bn1.scale, bn1.shift), stats=stats[1] if training else None,
-                        ntaps=kt, stride=stride, pad=pad)
+        if training and not BN_LAUNCHES:
+            # train mode: BN1 is finished by the temporal convolution's own launch (from the sums gcn_fused gathered)
+            o, bn1 = P.conv_rows_bn(y, packs[1][0], Cout, To, stats[0], f32(g1), f32(b1), rm1, rv1, B * T * V, bias=f32(bt),
+                                    stats=stats[1], ntaps=kt, stride=stride, pad=pad)
+        else:
+            bn1 = P.bn_finalize(stats[0] if training else None, B * T * V, f32(g1), f32(b1), rm1, rv1, training)
+            o = P.conv_rows(y, packs[1][0], Cout, To, bias=f32(bt), pro=(bn1.scale, bn1.shift), stats=stats[1] if training else None,
+                            ntaps=kt, stride=stride, pad=pad)
         # train mode: BN2 and the residual branch's BatchNorm are finished inside the output stage's launch (it derives
         # their coefficients from the convolutions' sums); eval mode reads the running statistics with bn_finalize
         fold = training and not BN_LAUNCHES and Cout <= 512      # the folded launch keeps its coefficient table in LDS

@@ -21,6 +21,8 @@ _vp, _i, _f, _d, _sz, _u32 = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_siz
 _SIGS = {
     "stgcn_conv_rows": [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp,
                         _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "stgcn_conv_rows_bn": [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _d, _f, _f, _vp,
+                           _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "stgcn_conv_wgrad": [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp],
     "stgcn_gcn_fused": [_i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "stgcn_gcn_agrad": [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp],

@@ -291,6 +291,20 @@ def conv_rows(x, w_packed, Cout, Tout, bias=None, pro=None, epilogue=L.EPI_PLAIN
     return out
 
 
+def conv_rows_bn(x, w_packed, Cout, Tout, stats_in, gamma, beta, rmean, rvar, count, bias=None, stats=None,
+                 ntaps=1, stride=1, pad=0, dil=1, momentum=0.1, eps=1e-5):
+    """Forward temporal convolution whose BatchNorm + ReLU prologue is finished inside the launch (train mode):
+    stats_in = the double sums [2*Cin] of x over `count` rows.  -> out, BnParams of the prologue's BatchNorm."""
+    B, Cin, Tin, V = x.shape
+    out = new_act(B, Cout, Tout, V, x.dtype, x.device)
+    bn = BnParams(Cin, x.device)
+    _launch((str(x.dtype), "F", L.EPI_PLAIN, B, Tin, Tout, V, Cin, Cout, ntaps, stride, True),
+            "stgcn_conv_rows", L.dtype_code(x.dtype), L.ptr(x), L.ptr(w_packed), L.ptr(out), L.ptr(bias),
+            L.ptr(stats_in), L.ptr(gamma), L.ptr(beta), L.ptr(rmean), L.ptr(rvar), L.ptr(bn.mean), float(count), float(momentum), float(eps),
+            L.ptr(stats), B, Tin, Tout, V, Cin, Cout, ntaps, stride, pad, dil, L.stream_ptr(), entry="stgcn_conv_rows_bn")
+    return out, bn
+
+
 def conv_wgrad(x, dout, ntaps, stride, pad, dil=1, pro=None):
     """-> dW [Cout, Cin, ntaps, 1] float32."""
     B, Cin, Tin, V = x.shape

@@ -624,3 +624,38 @@ def test_block_out_fwd_with_batchnorm_in_the_launch(rt, Cc, shape, with_r, dtype
     # and the statistics themselves against float64
     mean64 = o.double().mean(dim=(0, 2, 3)).cpu()
     assert rel(cn2.mean, mean64) < 1e-5
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("case", [(2, 64, 64, 20, 25, 9, 1), (3, 256, 256, 40, 18, 9, 1), (2, 128, 128, 37, 25, 9, 2), (1, 128, 64, 12, 18, 9, 1),
+                                  (2, 64, 40, 33, 25, 9, 1), (2, 128, 256, 75, 25, 5, 1)], ids=lambda c: "x".join(map(str, c)))
+def test_conv_rows_with_batchnorm_in_the_launch(rt, case, dtype):
+    """stgcn_conv_rows_bn (prologue coefficients derived from the sums inside the launch, in each of the four forward
+    convolution kernels) against stgcn_bn_finalize followed by stgcn_conv_rows: output, output statistics, mean / rstd /
+    scale / shift and running statistics bit for bit."""
+    B, Cin, Cout, T, V, kt, stride = case
+    pad = (kt - 1) // 2
+    To = O.tconv_out_len(T, kt, stride, pad)
+    x = to_dev(t64((B, Cin, T, V), 9401, -2, 2), dtype)
+    W = t64((Cout, Cin, kt), 9402) * (1.5 / np.sqrt(Cin * kt))
+    wp = rt.pack_conv_w(W[..., None].to(DEV).float(), dtype)
+    f = lambda tag, lo, hi: t64((Cin,), tag, lo, hi).float().to(DEV)
+    gamma, beta, bias = f(9403, 0.5, 1.5), f(9404, -0.3, 0.3), t64((Cout,), 9405, -0.2, 0.2).float().to(DEV)
+    x64 = x.double()
+    sums = torch.cat([x64.sum(dim=(0, 2, 3)), (x64 * x64).sum(dim=(0, 2, 3))]).contiguous()
+    rows = B * T * V
+    for path in conv_paths(dtype, Cout):
+        with path:
+            rm, rv = f(9406, -0.1, 0.1), f(9407, 0.5, 1.5)
+            bn = rt.bn_finalize(sums, rows, gamma, beta, rm, rv, True)
+            st = torch.zeros(2 * Cout, dtype=torch.float64, device=DEV)
+            want = rt.conv_rows(x, wp, Cout, To, bias=bias, pro=(bn.scale, bn.shift), stats=st, ntaps=kt, stride=stride, pad=pad)
+            qm, qv = f(9406, -0.1, 0.1), f(9407, 0.5, 1.5)
+            st2 = torch.zeros(2 * Cout, dtype=torch.float64, device=DEV)
+            got, cn = rt.conv_rows_bn(x, wp, Cout, To, sums, gamma, beta, qm, qv, rows, bias=bias, stats=st2, ntaps=kt, stride=stride, pad=pad)
+            torch.cuda.synchronize()
+        assert torch.equal(got, want)
+        for name in ("mean", "rstd", "scale", "shift"):
+            assert torch.equal(getattr(cn, name), getattr(bn, name)), name
+        assert torch.equal(qm, rm) and torch.equal(qv, rv)
+        assert rel(st2, st) < 1e-12                       # the sums are exact up to the order of the double atomics

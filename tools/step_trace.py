@@ -1,5 +1,5 @@
 """Per-step launch statistics from a rocprofv3 --kernel-trace CSV of bench.py: launches, busy time, gaps, and the
-kernels shorter than 20 us.  usage: step_trace.py kernel_trace.csv [skip]
+kernels shorter than 20 us.  usage: step_trace.py kernel_trace.csv [skip [sequence]]   (sequence: also every launch in order)
 
 A step ends with its sgd_kernel launch.  bench.py runs, after its timed steps, min(steps, 5) launch-by-launch steps
 that price the dominant kernel; `skip` (default 5) steps are dropped from the end of the trace so that the step
@@ -31,5 +31,9 @@ for k, v in sorted(small, key=lambda kv: -kv[1][1])[:16]:
 print("largest gaps:")
 for g, i in sorted(((g, i) for i, g in enumerate(gaps)), reverse=True)[:10]:
     print("  %6.1f us  after %-40s before %s" % (g / 1e3, step[i]["Kernel_Name"][:40], step[i + 1]["Kernel_Name"][:40]))
+if len(sys.argv) > 3 and sys.argv[3] == "sequence":
+    print("launch sequence of the step (us, kernel):")
+    for r in step:
+        print("  %7.1f  %s" % (dur(r) / 1e3, r["Kernel_Name"][:110]))
 hist = collections.Counter(min(int(g / 1000), 10) for g in gaps if g > 0)
 print("gap histogram (us: count):", sorted(hist.items()))

@@ -183,11 +183,12 @@ int stgcn_block_out_fwd_bn(int dtype, const void* o, const void* res, void* out,
 /* Backward of the stage above.  pass 0: per-channel sums (stats2, statsr).  pass 1: dO (BatchNorm backward of the
  * main branch), dR (same for a conv residual), g (= masked incoming gradient, for an identity residual), the
  * bias gradients of the two convolutions (dbias_*: double[C] sums accumulated with atomics, zeroed by the caller) and,
- * when asked for, the BatchNorm parameter gradients read off the sums of pass 0 (dbeta = sum, dgamma = sum*xhat).  The incoming gradient is dout and/or dpool (float32 [B][C],
- * constant over (t,v): the gradient of the global average pool).  The ReLU and dropout decisions come from relu_mask when
+ * when asked for, the BatchNorm parameter gradients read off the sums of pass 0 (dbeta = sum, dgamma = sum*xhat).  The incoming gradient is dout and/or
+ * dpool (float32 [B][C], constant over (t,v): every row of sample b receives dpool[b][c] * dpool_scale -- the gradient of the
+ * global average pool when dpool is the gradient of the pooled mean and dpool_scale = 1 / rows_per_sample).  The ReLU and dropout decisions come from relu_mask when
  * given (then out may be null), else from out and the dropout hash.
  * Replaces: autograd of net/st_gcn.py:169-170, 193-197 (and of F.avg_pool2d, st_gcn.py:85, for dpool). */
-int stgcn_block_out_bwd(int dtype, int pass, const void* dout, const float* dpool, size_t rows_per_sample,
+int stgcn_block_out_bwd(int dtype, int pass, const void* dout, const float* dpool, size_t rows_per_sample, float dpool_scale,
                         const void* out, const void* relu_mask, const void* o, const void* r,
                         const float* mean2, const float* rstd2, const float* gamma2,
                         const float* meanr, const float* rstdr, const float* gammar,
@@ -225,8 +226,20 @@ int stgcn_pool_fwd(int dtype, const void* feat, float* pooled, int B, int R, int
 int stgcn_pool_bwd(int dtype, const float* dpm, void* dfeat, int B, int R, int C, int M, void* stream);
 int stgcn_head_fc_fwd(const float* pooled, const float* W, const float* bias, float* logits,
                       int N, int M, int C, int ncls, void* stream);
-int stgcn_head_fc_bwd(const float* dlogits, const float* pooled, const float* W, float* dW, float* db, float* dpm,
+/* dpm [N][C]: gradient of the per-clip mean over persons; dpooled [N*M][C] = dpm / M per person (either may be null). */
+int stgcn_head_fc_bwd(const float* dlogits, const float* pooled, const float* W, float* dW, float* db, float* dpm, float* dpooled,
                       int N, int M, int C, int ncls, void* stream);
+
+/* out[i][e] = a[e] * inputs[i][e], e < len, for n <= 16 inputs in one launch (a null input gives zeros).  `inputs` is a
+ * HOST array of n device pointers (copied into the launch).  Forward: a = A, inputs = the blocks' edge_importance
+ * parameters; backward: inputs = the blocks' adjacency gradients.
+ * Replaces: self.A * importance of every block (net/st_gcn.py:81-82) and its autograd. */
+int stgcn_mul_many(const float* a, const float* const* inputs, int n, float* out, size_t len, void* stream);
+
+/* loss[0] = mean over n of -log softmax(logits[n])[labels[n]] and dlogits = (softmax - onehot) / N, one launch.
+ * labels: int64, every one in [0, ncls) (no ignore_index); N <= 8192.
+ * Replaces: nn.CrossEntropyLoss() of the training step (processor/recognition.py:44, 91) and its autograd. */
+int stgcn_cross_entropy(const float* logits, const int64_t* labels, float* loss, float* dlogits, int N, int ncls, void* stream);
 
 /* Re-packs every convolution weight of a model in one launch.  table: ndesc descriptors in device memory, each
  * 10 x 8 bytes { const float* src; void* w; void* wt; int64 G, Cout, Cin, Cinp, sg, sco, sci }: element (g, co, ci) =

@@ -303,7 +303,7 @@ extern "C" int stgcn_block_out_fwd_bn(int dtype, const void* o, const void* res,
 //   stats2 = [sum gd, sum gd*ohat]  (ohat = (o - mean2) * rstd2)
 //   statsr = [sum g,  sum g*rhat]   (only for the conv residual: rhat = (r - meanr) * rstdr)
 struct BlockOutBwdArgs {
-    const void* dout; const float* dpool; size_t rows_per_sample;
+    const void* dout; const float* dpool; size_t rows_per_sample; float dpool_scale;
     const void* out; const uint16_t* mask; const void* o; const void* r;
     const float* mean2; const float* rstd2; const float* gamma2;
     const float* meanr; const float* rstdr; const float* gammar;
@@ -344,7 +344,7 @@ __device__ __forceinline__ void piece_dout(const BlockOutBwdArgs& a, const Block
     if (a.dpool) {
         const float* q = a.dpool + (row / a.rows_per_sample) * a.C + cv * VEC;
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) d[j] += q[j];
+        for (int j = 0; j < VEC; ++j) d[j] = fmaf(q[j], a.dpool_scale, d[j]);
     }
 }
 
@@ -555,7 +555,7 @@ static void block_out_bwd_launch(const BlockOutBwdArgs& a, int pass, hipStream_t
     }
 }
 
-extern "C" int stgcn_block_out_bwd(int dtype, int pass, const void* dout, const float* dpool, size_t rows_per_sample,
+extern "C" int stgcn_block_out_bwd(int dtype, int pass, const void* dout, const float* dpool, size_t rows_per_sample, float dpool_scale,
                                    const void* out, const void* relu_mask, const void* o, const void* r,
                                    const float* mean2, const float* rstd2, const float* gamma2,
                                    const float* meanr, const float* rstdr, const float* gammar,
@@ -567,7 +567,7 @@ extern "C" int stgcn_block_out_bwd(int dtype, int pass, const void* dout, const 
     if (dpool && rows_per_sample == 0) return STGCN_ERR_ARG;
     if (r && (!meanr || !rstdr || !statsr)) return STGCN_ERR_ARG;
     BlockOutBwdArgs a;
-    a.dout = dout; a.dpool = dpool; a.rows_per_sample = rows_per_sample; a.out = out; a.mask = (const uint16_t*)relu_mask; a.o = o; a.r = r; a.mean2 = mean2; a.rstd2 = rstd2; a.gamma2 = gamma2;
+    a.dout = dout; a.dpool = dpool; a.rows_per_sample = rows_per_sample; a.dpool_scale = dpool_scale; a.out = out; a.mask = (const uint16_t*)relu_mask; a.o = o; a.r = r; a.mean2 = mean2; a.rstd2 = rstd2; a.gamma2 = gamma2;
     a.meanr = meanr; a.rstdr = rstdr; a.gammar = gammar; a.stats2 = stats2; a.statsr = statsr;
     a.dO = dO; a.dR = dR; a.g = g; a.dbias_o = dbias_o; a.dbias_r = dbias_r;
     a.dgamma2 = dgamma2; a.dbeta2 = dbeta2; a.dgammar = dgammar; a.dbetar = dbetar;
@@ -969,9 +969,11 @@ __global__ void head_fc_fwd_kernel(const float* pooled, const float* W, const fl
         logits[(size_t)n * ncls + j] = s;
     }
 }
-// dW[j][c] = sum_n dlog[n][j]*pm[n][c]; db[j] = sum_n dlog[n][j]; dpm[n][c] = sum_j dlog[n][j] W[j][c]
+// dW[j][c] = sum_n dlog[n][j]*pm[n][c]; db[j] = sum_n dlog[n][j]; dpm[n][c] = sum_j dlog[n][j] W[j][c];
+// dpooled[n*M + m][c] = dpm[n][c] / M (every person gets 1/M of its clip's gradient).  dpm / dpooled: either may be null.
 __global__ void head_fc_bwd_kernel(const float* __restrict__ dlog, const float* __restrict__ pooled, const float* __restrict__ W,
-                                   float* __restrict__ dW, float* __restrict__ db, float* __restrict__ dpm, int N, int M, int C, int ncls) {
+                                   float* __restrict__ dW, float* __restrict__ db, float* __restrict__ dpm, float* __restrict__ dpooled,
+                                   int N, int M, int C, int ncls) {
     const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t nW = (size_t)ncls * C, nP = (size_t)N * C;
     if (tid < nW) {
@@ -1003,7 +1005,11 @@ __global__ void head_fc_bwd_kernel(const float* __restrict__ dlog, const float* 
         const int n = (int)(i / C), c = (int)(i % C);
         float s = 0.f;
         for (int j = 0; j < ncls; ++j) s = fmaf(dlog[(size_t)n * ncls + j], W[(size_t)j * C + c], s);
-        dpm[i] = s;
+        if (dpm) dpm[i] = s;
+        if (dpooled) {
+            const float sp = s / (float)M;
+            for (int mm = 0; mm < M; ++mm) dpooled[((size_t)n * M + mm) * C + c] = sp;
+        }
     } else if (tid < nW + nP + ncls) {
         const int j = (int)(tid - nW - nP);
         float s = 0.f;
@@ -1030,11 +1036,11 @@ extern "C" int stgcn_head_fc_fwd(const float* pooled, const float* W, const floa
     hipLaunchKernelGGL(head_fc_fwd_kernel, dim3(N), dim3(256), C * sizeof(float), (hipStream_t)stream, pooled, W, bias, logits, N, M, C, ncls);
     return hipGetLastError() == hipSuccess ? STGCN_OK : STGCN_ERR_LAUNCH;
 }
-extern "C" int stgcn_head_fc_bwd(const float* dlogits, const float* pooled, const float* W, float* dW, float* db, float* dpm,
+extern "C" int stgcn_head_fc_bwd(const float* dlogits, const float* pooled, const float* W, float* dW, float* db, float* dpm, float* dpooled,
                                  int N, int M, int C, int ncls, void* stream) {
-    if (!dlogits || !pooled || !W || !dW || !db || !dpm) return STGCN_ERR_ARG;
+    if (!dlogits || !pooled || !W || !dW || !db || (!dpm && !dpooled) || M < 1) return STGCN_ERR_ARG;
     const size_t total = (size_t)ncls * C + (size_t)N * C + ncls;
-    hipLaunchKernelGGL(head_fc_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dlogits, pooled, W, dW, db, dpm, N, M, C, ncls);
+    hipLaunchKernelGGL(head_fc_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dlogits, pooled, W, dW, db, dpm, dpooled, N, M, C, ncls);
     return hipGetLastError() == hipSuccess ? STGCN_OK : STGCN_ERR_LAUNCH;
 }
 extern "C" int stgcn_pool_bwd(int dtype, const float* dpm, void* dfeat, int B, int R, int C, int M, void* stream) {
@@ -1044,6 +1050,70 @@ extern "C" int stgcn_pool_bwd(int dtype, const float* dpm, void* dfeat, int B, i
     if (dtype == STGCN_BF16) { if (!ew_ok<bf16>(C)) return STGCN_ERR_ARG; hipLaunchKernelGGL(pool_bwd_kernel<bf16>, grid, dim3(256), 0, (hipStream_t)stream, dpm, (bf16*)dfeat, R, C, M, scale); }
     else if (dtype == STGCN_F32) { if (!ew_ok<float>(C)) return STGCN_ERR_ARG; hipLaunchKernelGGL(pool_bwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, dpm, (float*)dfeat, R, C, M, scale); }
     else return STGCN_ERR_ARG;
+    return hipGetLastError() == hipSuccess ? STGCN_OK : STGCN_ERR_LAUNCH;
+}
+
+// ------------------------------------------------------------------------------------------
+// out[i][e] = a[e] * in_i[e] for up to MM_MAX inputs in one launch (in_i null: zeros).  A * importance_i of every block
+// (net/st_gcn.py:81-82 multiplies per block) and, backward, A * dA_i.
+constexpr int MM_MAX = 16;
+struct MulManyArgs { const float* a; const float* in[MM_MAX]; float* out; unsigned len; int n; };
+__global__ __launch_bounds__(256) void mul_many_kernel(MulManyArgs m) {
+    const unsigned e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= m.len) return;
+    const float av = m.a[e];
+    for (int i = 0; i < m.n; ++i) {
+        const float* p = m.in[i];
+        m.out[(size_t)i * m.len + e] = p ? av * p[e] : 0.f;
+    }
+}
+extern "C" int stgcn_mul_many(const float* a, const float* const* inputs, int n, float* out, size_t len, void* stream) {
+    if (!a || !inputs || !out || n < 1 || n > MM_MAX || len == 0 || len > 0x7fffffffu) return STGCN_ERR_ARG;
+    MulManyArgs m{};
+    m.a = a; m.out = out; m.len = (unsigned)len; m.n = n;
+    for (int i = 0; i < n; ++i) m.in[i] = inputs[i];
+    hipLaunchKernelGGL(mul_many_kernel, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, (hipStream_t)stream, m);
+    return hipGetLastError() == hipSuccess ? STGCN_OK : STGCN_ERR_LAUNCH;
+}
+
+// ------------------------------------------------------------------------------------------
+// Mean cross-entropy of logits [N][ncls] against labels [N] and its gradient (softmax - onehot) / N in one launch:
+// one wave per sample (lanes over classes, fixed butterflies), samples dealt to the four waves of ONE workgroup, the
+// per-sample losses added in sample order -- the same bits every run.
+__global__ __launch_bounds__(256) void cross_entropy_kernel(const float* __restrict__ logits, const long long* __restrict__ labels,
+                                                            float* __restrict__ loss, float* __restrict__ dlogits, int N, int ncls) {
+    extern __shared__ float per_sample[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float inv_n = 1.f / (float)N;
+    for (int n = wave; n < N; n += 4) {
+        const float* x = logits + (size_t)n * ncls;
+        float mx = -INFINITY;
+        for (int j = lane; j < ncls; j += 64) mx = fmaxf(mx, x[j]);
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d));
+        float se = 0.f;
+        for (int j = lane; j < ncls; j += 64) se += expf(x[j] - mx);
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) se += __shfl_xor(se, d);
+        const float lse = logf(se);
+        const int y = (int)labels[n];
+        for (int j = lane; j < ncls; j += 64) {
+            const float p = expf(x[j] - mx - lse);
+            dlogits[(size_t)n * ncls + j] = (p - (j == y ? 1.f : 0.f)) * inv_n;
+        }
+        if (lane == 0) per_sample[n] = -(x[y] - mx - lse);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float s = 0.f;
+        for (int n = 0; n < N; ++n) s += per_sample[n];
+        *loss = s * inv_n;
+    }
+}
+extern "C" int stgcn_cross_entropy(const float* logits, const int64_t* labels, float* loss, float* dlogits, int N, int ncls, void* stream) {
+    if (!logits || !labels || !loss || !dlogits || N < 1 || ncls < 1 || N > 8192) return STGCN_ERR_ARG;
+    hipLaunchKernelGGL(cross_entropy_kernel, dim3(1), dim3(256), (size_t)N * sizeof(float), (hipStream_t)stream,
+                       logits, (const long long*)labels, loss, dlogits, N, ncls);
     return hipGetLastError() == hipSuccess ? STGCN_OK : STGCN_ERR_LAUNCH;
 }
 

@@ -258,7 +258,8 @@ class Trainer:
         self.flat = FlatParams(model, reverse_execution_order(model))
         self.bucketer = GradBucketer(self.flat, bucket_bytes)
         self.opt = SGD(self.flat, lr, momentum, weight_decay, nesterov)
-        self.loss_fn = torch.nn.CrossEntropyLoss()
+        from . import functional as F_
+        self.loss_fn = F_.cross_entropy          # nn.CrossEntropyLoss() with its defaults, one launch each way
         self.use_graph = bool(graph)
         self.split = split                    # capture the step as two graphs: None = when there is more than one rank
         self._graphs = {}                     # (data shape, label shape) -> (graph, static data, static label, static loss)

@@ -268,8 +268,8 @@ class StGcnBlockFn(torch.autograd.Function):
         if dout is not None:
             dout = P.cl(dout.to(dtype))
         dpool = None
-        if dpooled is not None:                         # d(mean over T*V): constant over (t, v), kept in float32
-            dpool = (dpooled.float() / float(To * V)).contiguous()
+        if dpooled is not None:                         # d(mean over T*V): constant over (t, v), kept in float32; the kernels scale it
+            dpool = dpooled.float().contiguous()
         f32 = lambda t: t.detach().float().contiguous()
         r_ = r if kind == "conv" else None
 
@@ -283,7 +283,7 @@ class StGcnBlockFn(torch.autograd.Function):
         with (P.deferred_sums(dev) if side is None else contextlib.nullcontext()):
             dO, dR, g, stats2, statsr, dbt, dbr_f, (dg2, db2, dgr, dbetar) = P.block_out_bwd(
                 dout, out, o, r_, bn2, f32(g2), bnr, f32(gr) if kind == "conv" else None, kind == "identity" and not mask_in_dx,
-                p, seed, training, dpool=dpool, relu_mask=ctx.relu_mask, want_bn_grads=True)
+                p, seed, training, dpool=dpool, relu_mask=ctx.relu_mask, want_bn_grads=True, dpool_scale=1.0 / float(To * V))
 
             # temporal conv: weight grad (input = relu(bn1(y)) recomputed in the prologue), then data grad fused with
             # the ReLU mask and the BN1-backward sums
@@ -329,31 +329,57 @@ class StGcnBlockFn(torch.autograd.Function):
 
 
 class EdgeImportanceFn(torch.autograd.Function):
-    """A * importance_i for every block at once (net/st_gcn.py:81-82 of the reference multiplies per block):
-    two launches forward (stack, multiply) and two backward instead of one multiply per block each way.
-    Returns one [K,V,V] float32 tensor per block."""
+    """A * importance_i for every block at once (net/st_gcn.py:81-82 of the reference multiplies per block): one
+    launch forward and one backward (stgcn_mul_many) instead of one multiply per block each way.  Returns one [K,V,V]
+    float32 tensor per block."""
 
     @staticmethod
     def forward(ctx, A, *importances):
-        imp = torch.stack([p.detach().float() for p in importances])
         ctx.save_for_backward(A)
-        return tuple((A.detach().float().unsqueeze(0) * imp).unbind(0))
+        a = A.detach().float().contiguous()
+        imps = [p.detach().float().contiguous() for p in importances]
+        out = P.mul_many(a, imps) if a.is_cuda else None
+        if out is None:
+            out = a.unsqueeze(0) * torch.stack(imps)
+        return tuple(out.unbind(0))
 
     @staticmethod
     def backward(ctx, *grads):
         (A,) = ctx.saved_tensors
         if all(g is None for g in grads):
             return (None,) * (1 + len(grads))
-        zero = None
-        gl = []
-        for g in grads:
-            if g is None:
-                if zero is None:
-                    zero = torch.zeros_like(A, dtype=torch.float32)
-                g = zero
-            gl.append(g.float())
-        d = torch.stack(gl) * A.detach().float().unsqueeze(0)
+        a = A.detach().float().contiguous()
+        gl = [None if g is None else g.float().contiguous() for g in grads]
+        d = P.mul_many(a, gl) if a.is_cuda else None
+        if d is None:
+            zero = torch.zeros_like(a)
+            d = torch.stack([zero if g is None else g for g in gl]) * a.unsqueeze(0)
         return (None,) + tuple(d.unbind(0))
+
+
+class CrossEntropyFn(torch.autograd.Function):
+    """Mean cross-entropy of the logits (nn.CrossEntropyLoss() with its defaults, processor/recognition.py:44, 91): loss
+    and d loss / d logits from one launch."""
+
+    @staticmethod
+    def forward(ctx, logits, labels):
+        loss, dlogits = P.cross_entropy(logits.detach().float().contiguous(), labels.contiguous())
+        ctx.save_for_backward(dlogits)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (dlogits,) = ctx.saved_tensors
+        return dlogits * g, None
+
+
+def cross_entropy(logits, labels):
+    """nn.CrossEntropyLoss()(logits, labels) for float32 logits [N, ncls] on the GPU and int64 labels; anything else goes
+    to torch's own."""
+    if logits.is_cuda and logits.dim() == 2 and logits.dtype == torch.float32 and labels.dtype == torch.int64 and labels.dim() == 1 \
+            and logits.shape[0] <= 8192:
+        return CrossEntropyFn.apply(logits, labels)
+    return torch.nn.functional.cross_entropy(logits, labels)
 
 
 class DataBnFn(torch.autograd.Function):
@@ -432,7 +458,6 @@ class HeadFn(torch.autograd.Function):
         dlogits = dlogits.float().contiguous()
         dW = torch.empty((ncls, Cc), dtype=torch.float32, device=dev)
         db = torch.empty((ncls,), dtype=torch.float32, device=dev)
-        dpm = torch.empty((N, Cc), dtype=torch.float32, device=dev)
-        L.call("stgcn_head_fc_bwd", L.ptr(dlogits), L.ptr(pooled), L.ptr(Wf), L.ptr(dW), L.ptr(db), L.ptr(dpm), N, M, Cc, ncls, L.stream_ptr())
-        dpooled = (dpm / float(M)).repeat_interleave(M, dim=0)      # [N*M, C]: every person gets 1/M of its clip's gradient
+        dpooled = torch.empty((N * M, Cc), dtype=torch.float32, device=dev)     # every person gets 1/M of its clip's gradient
+        L.call("stgcn_head_fc_bwd", L.ptr(dlogits), L.ptr(pooled), L.ptr(Wf), L.ptr(dW), L.ptr(db), None, L.ptr(dpooled), N, M, Cc, ncls, L.stream_ptr())
         return dpooled, dW.reshape(wshape), db, None, None

@@ -38,7 +38,7 @@ _SIGS = {
     "stgcn_block_out_fwd": [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _f, _u32, _vp, _vp],
     "stgcn_block_out_fwd_bn": [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f,
                                _sz, _i, _f, _u32, _vp, _vp],
-    "stgcn_block_out_bwd": [_i, _i, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+    "stgcn_block_out_bwd": [_i, _i, _vp, _vp, _sz, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                             _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _f, _u32, _d, _i, _vp],
     "stgcn_bn_bwd_apply": [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _d, _vp, _vp, _sz, _i, _i, _vp],
     "stgcn_augment": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
@@ -47,8 +47,10 @@ _SIGS = {
     "stgcn_data_bn_bwd": [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "stgcn_pool_fwd": [_i, _vp, _vp, _i, _i, _i, _vp],
     "stgcn_head_fc_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
-    "stgcn_head_fc_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "stgcn_head_fc_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "stgcn_pool_bwd": [_i, _vp, _vp, _i, _i, _i, _i, _vp],
+    "stgcn_mul_many": [_vp, _vp, _i, _vp, _sz, _vp],
+    "stgcn_cross_entropy": [_vp, _vp, _vp, _vp, _i, _i, _vp],
     "stgcn_pack_weights": [_i, _vp, _i, _sz, _vp],
     "stgcn_sgd_step": [_vp, _vp, _vp, _sz, _f, _f, _f, _i, _i, _f, _vp],
     "stgcn_probe_tr16": [_vp, _vp],

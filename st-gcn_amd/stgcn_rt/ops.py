@@ -420,10 +420,10 @@ def block_out_fwd_bn(o, res, stats2, gamma2, beta2, rm2, rv2, statsr, gammar, be
 
 
 def block_out_bwd(dout, out, o, r, bn2, gamma2, bnr, gammar, want_g, drop_p, seed, training, dpool=None, relu_mask=None,
-                  want_bn_grads=False):
+                  want_bn_grads=False, dpool_scale=1.0):
     """-> dO, dR (or None), g (or None), stats2 [2,C] (sum gd, sum gd*ohat), statsr, dbias_o, dbias_r (float32 [C]);
     with want_bn_grads additionally (dgamma2, dbeta2, dgammar, dbetar) as float32, written by the apply pass.
-    The incoming gradient is dout (stored tensor) and/or dpool [B,C] float32, constant over (t,v).  The ReLU
+    The incoming gradient is dout (stored tensor) and/or dpool [B,C] float32 times dpool_scale, constant over (t,v).  The ReLU
     decisions are read from relu_mask (as written by block_out_fwd) when given, else from out."""
     B, Cc, T, V = o.shape
     rows = B * T * V
@@ -432,7 +432,7 @@ def block_out_bwd(dout, out, o, r, bn2, gamma2, bnr, gammar, want_g, drop_p, see
     dbo, dbr = acc[4], acc[5]                             # zeroed double sums
     has_r = r is not None
     bng = torch.empty((4, Cc), dtype=torch.float32, device=o.device) if want_bn_grads else None
-    args = [L.dtype_code(o.dtype), 0, L.ptr(dout), L.ptr(dpool), T * V, L.ptr(out) if relu_mask is None else None, L.ptr(relu_mask), L.ptr(o), L.ptr(r), L.ptr(bn2.mean), L.ptr(bn2.rstd), L.ptr(gamma2),
+    args = [L.dtype_code(o.dtype), 0, L.ptr(dout), L.ptr(dpool), T * V, float(dpool_scale), L.ptr(out) if relu_mask is None else None, L.ptr(relu_mask), L.ptr(o), L.ptr(r), L.ptr(bn2.mean), L.ptr(bn2.rstd), L.ptr(gamma2),
             L.ptr(bnr.mean) if has_r else None, L.ptr(bnr.rstd) if has_r else None, L.ptr(gammar) if has_r else None,
             L.ptr(stats2), L.ptr(statsr) if has_r else None, None, None, None, L.ptr(dbo), L.ptr(dbr) if has_r else None,
             L.ptr(bng[0]) if want_bn_grads else None, L.ptr(bng[1]) if want_bn_grads else None,
@@ -443,7 +443,7 @@ def block_out_bwd(dout, out, o, r, bn2, gamma2, bnr, gammar, want_g, drop_p, see
     dR = new_act(B, Cc, T, V, o.dtype, o.device) if has_r else None
     g = new_act(B, Cc, T, V, o.dtype, o.device) if want_g else None
     args[1] = 1
-    args[17], args[18], args[19] = L.ptr(dO), L.ptr(dR), L.ptr(g)
+    args[18], args[19], args[20] = L.ptr(dO), L.ptr(dR), L.ptr(g)
     _launch((str(o.dtype), 1, rows, Cc, has_r, want_g), "stgcn_block_out_bwd", *args)
     # the bias sums leave this function (they become .grad of the conv biases): float32 memory of their own, not views
     # of the statistics arena, which the next training forward clears
@@ -466,6 +466,28 @@ def bn_bwd_apply(g, y, gamma, bn, stats, training, out=None, want_grads=False):
            L.ptr(stats), float(B * T * V), L.ptr(pg[0]) if want_grads else None, L.ptr(pg[1]) if want_grads else None,
            B * T * V, Cc, 1 if training else 0, L.stream_ptr())
     return (out, pg[0], pg[1]) if want_grads else out
+
+
+def mul_many(a, inputs):
+    """-> [n, *a.shape] float32 with out[i] = a * inputs[i] (None: zeros), one launch; None when the inputs are not what
+    the kernel takes (more than 16, another dtype, device or layout): the caller then multiplies with torch."""
+    n = len(inputs)
+    ok = lambda t: t is None or (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.shape == a.shape and t.device == a.device)
+    if not (1 <= n <= 16 and a.is_cuda and a.dtype == torch.float32 and a.is_contiguous() and all(ok(t) for t in inputs)):
+        return None
+    arr = (ctypes.c_void_p * n)(*[None if t is None else t.data_ptr() for t in inputs])
+    out = torch.empty((n,) + tuple(a.shape), dtype=torch.float32, device=a.device)
+    L.call("stgcn_mul_many", L.ptr(a), ctypes.addressof(arr), n, L.ptr(out), a.numel(), L.stream_ptr())
+    return out
+
+
+def cross_entropy(logits, labels):
+    """Mean cross-entropy of float32 logits [N, ncls] and int64 labels [N] -> (loss [], d loss / d logits [N, ncls])."""
+    N, ncls = logits.shape
+    loss = torch.empty((), dtype=torch.float32, device=logits.device)
+    dlogits = torch.empty((N, ncls), dtype=torch.float32, device=logits.device)
+    L.call("stgcn_cross_entropy", L.ptr(logits), L.ptr(labels), L.ptr(loss), L.ptr(dlogits), N, ncls, L.stream_ptr())
+    return loss, dlogits
 
 
 def sgd_step(params, grads, mom, lr, momentum, weight_decay, nesterov, first_step, grad_scale=1.0):

@@ -659,3 +659,30 @@ def test_conv_rows_with_batchnorm_in_the_launch(rt, case, dtype):
             assert torch.equal(getattr(cn, name), getattr(bn, name)), name
         assert torch.equal(qm, rm) and torch.equal(qv, rv)
         assert rel(st2, st) < 1e-12                       # the sums are exact up to the order of the double atomics
+
+
+def test_mul_many_and_cross_entropy(rt):
+    """stgcn_mul_many (A * importance of every block, and its backward) and stgcn_cross_entropy (loss and gradient of
+    nn.CrossEntropyLoss() with its defaults) against float64 evaluations of the same formulas."""
+    from stgcn_rt import functional as Fn
+    a = t64((3, 25, 25), 9501).float().to(DEV)
+    ins = [t64((3, 25, 25), 9510 + i).float().to(DEV) for i in range(10)]
+    out = rt.mul_many(a, ins)
+    assert torch.equal(out, torch.stack(ins) * a.unsqueeze(0))
+    ins[4] = None
+    out = rt.mul_many(a, ins)
+    assert not out[4].any() and torch.equal(out[5], ins[5] * a)
+    assert rt.mul_many(a, [a] * 17) is None and rt.mul_many(a, [a.double()]) is None
+
+    for N, ncls in ((64, 60), (5, 400), (1, 3), (130, 1000)):
+        logits = (t64((N, ncls), 9600 + N, -6, 6)).float().to(DEV).requires_grad_(True)
+        labels = torch.tensor([(7 * i + 3) % ncls for i in range(N)], dtype=torch.int64, device=DEV)
+        loss = Fn.cross_entropy(logits, labels)
+        (loss * 3.0).backward()
+        l64 = logits.detach().double().cpu().requires_grad_(True)
+        ref = torch.nn.functional.cross_entropy(l64, labels.cpu())
+        (ref * 3.0).backward()
+        assert abs(loss.item() - ref.item()) < 1e-6 * max(1.0, abs(ref.item()))
+        assert rel(logits.grad, l64.grad) < 1e-5
+        again = Fn.cross_entropy(logits.detach(), labels)
+        assert torch.equal(again, loss.detach())            # the same bits every run

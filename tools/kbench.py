@@ -90,7 +90,7 @@ def make(case, dtype):
         dbf = torch.zeros((2, Cc), dtype=torch.float64, device=DEV)
         dO, dR, g = torch.empty_like(o), torch.empty_like(o), torch.empty_like(o)
         ps = 0 if name.startswith("bob0") else 1
-        args = [L.dtype_code(o.dtype), ps, L.ptr(dout), None, Tt * V, None, L.ptr(mask), L.ptr(o), L.ptr(r), L.ptr(bn2.mean), L.ptr(bn2.rstd), L.ptr(g2),
+        args = [L.dtype_code(o.dtype), ps, L.ptr(dout), None, Tt * V, 1.0, None, L.ptr(mask), L.ptr(o), L.ptr(r), L.ptr(bn2.mean), L.ptr(bn2.rstd), L.ptr(g2),
                 L.ptr(bnr.mean) if has_r else None, L.ptr(bnr.rstd) if has_r else None, L.ptr(gr) if has_r else None,
                 L.ptr(acc[0:2]), L.ptr(acc[2:4]) if has_r else None,
                 L.ptr(dO) if ps else None, L.ptr(dR) if (ps and has_r) else None, L.ptr(g) if (ps and want_g) else None,

@@ -31,7 +31,7 @@ def make(case, dtype):
     name, Cin, Cout = parts[0], int(parts[1]), int(parts[2])
     stride = int(parts[3]) if len(parts) > 3 else 1
     Tin = int(parts[4]) if len(parts) > 4 else {64: 300, 128: 150, 256: 75}.get(Cin, 300)
-    if name in ("gcn_fused", "gcn_fused_add", "gcn_agrad", "gcn_wgrad"):
+    if name in ("gcn_fused", "gcn_fused_ns", "gcn_fused_add", "gcn_agrad", "gcn_wgrad"):
         x = act(Cin, Tin, dtype)
         adj = torch.rand((K, V, V), device=DEV) * 0.2
         W = torch.randn((K * Cout, Cin, 1, 1), device=DEV) * (1.0 / Cin ** 0.5)
@@ -41,6 +41,8 @@ def make(case, dtype):
         stats = torch.zeros(2 * Cout, dtype=torch.float64, device=DEV)
         if name == "gcn_fused":
             return lambda: R.gcn_fused(x, wp, adj, Cout, bias=bias, stats=stats)
+        if name == "gcn_fused_ns":                # without the BatchNorm statistics
+            return lambda: R.gcn_fused(x, wp, adj, Cout, bias=bias)
         if name == "gcn_fused_add":
             return lambda: R.gcn_fused(x, wp, adj, Cout, add=dy)
         if name == "gcn_agrad":

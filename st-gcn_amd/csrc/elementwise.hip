@@ -900,11 +900,12 @@ extern "C" int stgcn_data_bn_bwd(int dtype, const void* dx0, const float* x, con
 // ------------------------------------------------------------------------------------------
 // Head: global average pool over (T, V), mean over persons, 1x1 classifier.
 template <typename T, int NT = 256>
-__global__ __launch_bounds__(NT) void pool_fwd_kernel(const T* feat, float* pooled, int R, int C) {
-    // workgroup per sample b; feat [B][R][C].  One workgroup streams a whole sample (a fixed summation order), so the
-    // loads in flight are what counts: NT = 1024 threads, 8 loads each
+__global__ __launch_bounds__(NT) void pool_fwd_kernel(const T* feat, float* pooled, int R, int C, int Cw) {
+    // workgroup (b, s): sample b, channels [s * Cw, (s + 1) * Cw) of feat [B][R][C].  One workgroup streams all rows of its channels (a fixed summation order), so
+    // the loads in flight are what counts: NT = 1024 threads, 8 loads each
     constexpr int VEC = ET<T>::VEC;
-    RowMap<T, NT> m(C);
+    RowMap<T, NT> m(Cw);
+    feat += blockIdx.y * Cw; pooled += blockIdx.y * Cw;
     float s[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; ++j) s[j] = 0.f;
@@ -947,8 +948,14 @@ __global__ __launch_bounds__(NT) void pool_fwd_kernel(const T* feat, float* pool
 }
 extern "C" int stgcn_pool_fwd(int dtype, const void* feat, float* pooled, int B, int R, int C, void* stream) {
     if (!feat || !pooled || B < 1 || R < 1) return STGCN_ERR_ARG;
-    if (dtype == STGCN_BF16) { if (!ew_ok<bf16>(C)) return STGCN_ERR_ARG; hipLaunchKernelGGL((pool_fwd_kernel<bf16, 1024>), dim3(B), dim3(1024), 0, (hipStream_t)stream, (const bf16*)feat, pooled, R, C); }
-    else if (dtype == STGCN_F32) { if (!ew_ok<float>(C)) return STGCN_ERR_ARG; hipLaunchKernelGGL((pool_fwd_kernel<float, 1024>), dim3(B), dim3(1024), 0, (hipStream_t)stream, (const float*)feat, pooled, R, C); }
+    const int vec = dtype == STGCN_BF16 ? ET<bf16>::VEC : ET<float>::VEC;
+    // channel groups per sample: 128 channels per workgroup (the 256-channel output of the last block: two workgroups per
+    // sample, 256 for the 128 samples of a 64-clip step).  A function of C alone, so that a clip's sums are added in
+    // the same order whatever the batch.
+    const int S = (C % 128 == 0 && C / 128 <= 8 && 128 % vec == 0) ? C / 128 : 1;
+    const dim3 grid((unsigned)B, (unsigned)S);
+    if (dtype == STGCN_BF16) { if (!ew_ok<bf16>(C)) return STGCN_ERR_ARG; hipLaunchKernelGGL((pool_fwd_kernel<bf16, 1024>), grid, dim3(1024), 0, (hipStream_t)stream, (const bf16*)feat, pooled, R, C, C / S); }
+    else if (dtype == STGCN_F32) { if (!ew_ok<float>(C)) return STGCN_ERR_ARG; hipLaunchKernelGGL((pool_fwd_kernel<float, 1024>), grid, dim3(1024), 0, (hipStream_t)stream, (const float*)feat, pooled, R, C, C / S); }
     else return STGCN_ERR_ARG;
     return hipGetLastError() == hipSuccess ? STGCN_OK : STGCN_ERR_LAUNCH;
 }
@@ -1078,14 +1085,14 @@ extern "C" int stgcn_mul_many(const float* a, const float* const* inputs, int n,
 
 // ------------------------------------------------------------------------------------------
 // Mean cross-entropy of logits [N][ncls] against labels [N] and its gradient (softmax - onehot) / N in one launch:
-// one wave per sample (lanes over classes, fixed butterflies), samples dealt to the four waves of ONE workgroup, the
+// one wave per sample (lanes over classes, fixed butterflies), samples dealt to the sixteen waves of ONE workgroup, the
 // per-sample losses added in sample order -- the same bits every run.
-__global__ __launch_bounds__(256) void cross_entropy_kernel(const float* __restrict__ logits, const long long* __restrict__ labels,
+__global__ __launch_bounds__(1024) void cross_entropy_kernel(const float* __restrict__ logits, const long long* __restrict__ labels,
                                                             float* __restrict__ loss, float* __restrict__ dlogits, int N, int ncls) {
     extern __shared__ float per_sample[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float inv_n = 1.f / (float)N;
-    for (int n = wave; n < N; n += 4) {
+    for (int n = wave; n < N; n += 16) {
         const float* x = logits + (size_t)n * ncls;
         float mx = -INFINITY;
         for (int j = lane; j < ncls; j += 64) mx = fmaxf(mx, x[j]);
@@ -1112,7 +1119,7 @@ __global__ __launch_bounds__(256) void cross_entropy_kernel(const float* __restr
 }
 extern "C" int stgcn_cross_entropy(const float* logits, const int64_t* labels, float* loss, float* dlogits, int N, int ncls, void* stream) {
     if (!logits || !labels || !loss || !dlogits || N < 1 || ncls < 1 || N > 8192) return STGCN_ERR_ARG;
-    hipLaunchKernelGGL(cross_entropy_kernel, dim3(1), dim3(256), (size_t)N * sizeof(float), (hipStream_t)stream,
+    hipLaunchKernelGGL(cross_entropy_kernel, dim3(1), dim3(1024), (size_t)N * sizeof(float), (hipStream_t)stream,
                        logits, (const long long*)labels, loss, dlogits, N, ncls);
     return hipGetLastError() == hipSuccess ? STGCN_OK : STGCN_ERR_LAUNCH;
 }

@@ -278,9 +278,10 @@ class st_gcn(nn.Module):
         self._drop_step = None
 
     def _seed(self):
-        """Dropout seed of this block: a function of torch's seed, the block's position in the model and the
-        process's rank (data-parallel replicas draw different masks, as nn.DataParallel replicas do) -- nothing that
-        changes from run to run.  The position inside the stream of masks is the device-side step count."""
+        """Dropout seed of this block: a function of torch's seed (torch.manual_seed makes runs repeat; unseeded, torch
+        draws a fresh seed per process and so do the masks), the block's position in the model and the process's rank
+        (data-parallel replicas draw different masks, as nn.DataParallel replicas do).  The position inside the stream
+        of masks is the device-side step count."""
         rank = torch.distributed.get_rank() if torch.distributed.is_available() and torch.distributed.is_initialized() else 0
         return (torch.initial_seed() * 0x9E3779B1 + (self.block_index + 1) * 0x632BE5AB + rank * 0xC2B2AE35) & 0xFFFFFFFF
 

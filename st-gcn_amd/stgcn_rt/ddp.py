@@ -275,6 +275,11 @@ class Trainer:
     def graph_ready(self):
         return bool(self._graphs)
 
+    def graph_segments(self):
+        """Captured graphs per step: 2 when the step was captured in two segments (collectives between them), 1 for one
+        graph, 0 without a graph."""
+        return max((2 if isinstance(ent[0], tuple) else 1 for ent in self._graphs.values()), default=0)
+
     def _forward_backward(self, data, label):
         self.flat.zero_grad()
         out = self.model(data)

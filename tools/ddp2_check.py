@@ -128,14 +128,14 @@ def main():
     ls = torch.tensor([7, 21], device=dev)
     losses = [float(tr.step(xs, ls).detach()) for _ in range(5)]
     torch.cuda.synchronize()
-    assert tr.graph_ready()
+    assert tr.graph_ready() and tr.graph_segments() == 2      # two graphs, the first all-reduce issued between them
     replicas_identical("after graph replays")
     lt = torch.tensor(losses, dtype=torch.float64)
     alll = gather_cpu(lt, world, backend, dev)
     assert float((alll[0] - alll[1]).abs().min()) > 1e-6, ("same clips, same weights: losses differ only by the masks", alll)
     dist.barrier()
     if rank == 0:
-        print("graph replay: 5 steps, replicas bit-identical, per-rank losses", [[round(float(v), 4) for v in a] for a in alll])
+        print("graph replay (two graphs per step, the late blocks' all-reduce between them): 5 steps, replicas bit-identical, per-rank losses", [[round(float(v), 4) for v in a] for a in alll])
         print("DDP2_RANKS_OK backend=%s world=%d" % (backend, world))
     dist.destroy_process_group()
 

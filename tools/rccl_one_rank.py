@@ -54,6 +54,7 @@ def main():
                 by_hooks = list(tr.bucketer.launched)           # the first step is always launch by launch
         torch.cuda.synchronize()
         assert tr.graph_ready() == graph
+        assert tr.graph_segments() == (2 if (graph and force) else 1 if graph else 0), tr.graph_segments()
         return tr.flat.flat.detach().clone(), losses, by_hooks, len(tr.bucketer.buckets)
 
     for dtype in (torch.float32, torch.bfloat16):
@@ -63,8 +64,9 @@ def main():
             assert nb >= 3 and by_hooks == list(range(nb)), (by_hooks, nb)     # every bucket left from a backward hook, in order
             assert l_got == l_ref, (l_got, l_ref)
             assert torch.equal(got, ref), float((got - ref).abs().max())
-            print("%s graph=%s: %d buckets all-reduced over RCCL from the backward hooks; losses and parameters equal the "
-                  "collective-free trainer bit for bit" % (str(dtype).replace("torch.", ""), graph, nb))
+            print("%s graph=%s: %d buckets all-reduced over RCCL from the backward hooks%s; losses and parameters equal the "
+                  "collective-free trainer bit for bit" % (str(dtype).replace("torch.", ""), graph, nb,
+                  " in the two launch-by-launch steps, then the step replayed as two graphs with the late blocks' all-reduce between them" if graph else ""))
     dist.barrier()
     dist.destroy_process_group()
     print("RCCL_ONE_RANK_OK")
